@@ -1,0 +1,225 @@
+/*
+ * rtcore.h -- C ABI of the MI355X ray-tracing core (librtcore.so).
+ *
+ * The reference (sati290/rust-raytracer) is a single Rust binary with no FFI
+ * or plugin layer.  Its de-facto trace boundary is four methods on `Bvh` and
+ * the per-tile integrator function pointer chosen in `main`; each entry point
+ * below names the reference item it stands in for (paths relative to the
+ * reference repository root).  Signatures use plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or an RT_ERR_* code and never throws or
+ *     aborts across the ABI (the reference panics instead: src/scene.rs:31,48,
+ *     src/bvh/intersect1.rs:115 ArrayVec overflow); rt_last_error() returns a
+ *     thread-local message for the last failing call.
+ *   - "host" entry points take caller-owned host buffers and copy them; the
+ *     "_device" variants take device pointers of the context's GPU and run on
+ *     the given HIP stream (hipStream_t passed as void*, NULL = default
+ *     stream) without synchronising it.
+ *   - one in-flight call per rt_ctx; an rt_scene is immutable after creation.
+ */
+#ifndef RTCORE_H
+#define RTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID 1 /* bad argument                                   */
+#define RT_ERR_HIP 2     /* HIP runtime failure (message has the HIP text) */
+#define RT_ERR_NOMEM 3
+#define RT_ERR_LIMIT 4   /* size beyond a documented limit                 */
+
+#define RT_NO_HIT 0xFFFFFFFFu /* Option<u32>::None of src/bvh/intersect1.rs:109 */
+
+typedef struct rt_ctx rt_ctx;     /* one per GPU                         */
+typedef struct rt_scene rt_scene; /* device-resident BVH + triangles     */
+
+/* src/ray.rs:6-24 StreamRay, repr(C, align(16)), 48 bytes.  origin_far.w is
+ * the far distance and is shrunk to the hit distance by closest-hit calls;
+ * dir_recip_near.xyz = 1/direction (unclamped), .w = near. */
+typedef struct rt_stream_ray {
+    float origin_far[4];
+    float dir_recip_near[4];
+    float direction[4];
+} rt_stream_ray;
+
+/* src/trace_stats.rs:4-12.  The GPU traverses one ray per lane, so
+ * inner_visit == inner_rays and leaf_visit == leaf_rays here (as in the
+ * reference's single-ray traversal); total_rays, inner_rays, leaf_rays,
+ * leaf_objs and obj_intersect are the sums the reference counts per ray. */
+typedef struct rt_trace_stats {
+    uint64_t total_rays;
+    uint64_t inner_visit;
+    uint64_t inner_rays;
+    uint64_t leaf_visit;
+    uint64_t leaf_rays;
+    uint64_t leaf_objs;
+    uint64_t obj_intersect;
+} rt_trace_stats;
+
+/* src/bvh/build.rs:5-11 BvhStats */
+typedef struct rt_bvh_stats {
+    uint32_t num_leaves;
+    uint32_t num_objs;
+    uint32_t max_depth;
+    uint32_t max_objs;
+} rt_bvh_stats;
+
+typedef struct rt_scene_info {
+    uint32_t num_triangles;
+    uint32_t num_inner_nodes;
+    uint32_t root_ref;   /* canonical flat encoding, see rt_flat_node */
+    uint32_t root_count;
+    uint64_t device_bytes;
+} rt_scene_info;
+
+/* Canonical flattened tree (pre-order, left child follows its parent) for
+ * inspection and builder parity checks.  bx/by/bz lanes are
+ * {minL,minR,maxL,maxR} (src/bvh.rs:19-23).  Child reference: bit 31 clear =
+ * inner node index; bit 31 set = leaf, low 31 bits = first slot in the
+ * leaf-ordered triangle array, *_count = number of triangles. */
+typedef struct rt_flat_node {
+    float bx[4];
+    float by[4];
+    float bz[4];
+    uint32_t left;
+    uint32_t right;
+    uint32_t left_count;
+    uint32_t right_count;
+} rt_flat_node;
+
+/* src/triangle_opt.rs:10-14 in leaf order plus the mesh triangle id that
+ * src/bvh.rs:32 keeps in object_indices. */
+typedef struct rt_flat_tri {
+    float v0[3];
+    float v0v1[3];
+    float v0v2[3];
+    uint32_t id;
+    uint32_t pad[2];
+} rt_flat_tri;
+
+/* Camera::new inputs, src/camera.rs:25 */
+typedef struct rt_camera {
+    float eye[3];
+    float target[3];
+    float up[3];
+    float fov_deg;
+} rt_camera;
+
+/* src/light.rs:4-16, intensity = color * power */
+typedef struct rt_light {
+    float pos[3];
+    float intensity[3];
+} rt_light;
+
+/* Arguments of the reference's integrator call (src/main.rs:143-149) plus the
+ * image size it hard-codes (src/main.rs:103-104) and the sharding this build
+ * adds.  Tiles are the reference's row-major tile_size x tile_size grid
+ * (src/main.rs:61-98); a call renders the tiles i with
+ * i % shard_count == shard_index, samples [sample_offset, sample_offset+samples)
+ * of each of their pixels.  Random numbers are keyed by (seed, pixel, sample,
+ * dimension), so the image does not depend on how a frame is split. */
+#define RT_RENDER_VISIT_STATS 1u /* fill the per-visit counters of rt_trace_stats, not only total_rays */
+
+typedef struct rt_render_params {
+    uint32_t width, height;
+    uint32_t samples;          /* src/args.rs:24, default 128           */
+    uint32_t sample_offset;
+    uint32_t max_bounces;      /* src/args.rs:27, default 2             */
+    uint32_t tile_size;        /* src/args.rs:30, default 16            */
+    uint32_t shard_index;
+    uint32_t shard_count;      /* 0 is read as 1                        */
+    uint32_t samples_per_pass; /* 0 = library default                   */
+    uint32_t flags;            /* RT_RENDER_*                           */
+    uint64_t seed;             /* src/args.rs:36, default 1235468       */
+} rt_render_params;
+
+const char *rt_last_error(void);
+const char *rt_version(void);
+
+/* No reference counterpart (the reference has no device).  device_id is a HIP
+ * device ordinal. */
+int rt_ctx_create(int device_id, rt_ctx **out);
+void rt_ctx_destroy(rt_ctx *ctx);
+/* Upper bound of paths per render pass (workspace is sized from it lazily). */
+int rt_ctx_set_max_paths(rt_ctx *ctx, uint64_t max_paths);
+
+/* Bvh::build, src/bvh/build.rs:45-63 (binned SAH, 8 buckets, leaf <= 8) on the
+ * indexed mesh of src/mesh.rs:9-15; flattens and uploads once.  positions:
+ * 3*num_vertices floats; indices: 3*num_triangles; geom_normals:
+ * 3*num_triangles (src/mesh.rs:180-188). */
+int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num_vertices,
+                    const uint32_t *indices, uint32_t num_triangles, const float *geom_normals,
+                    rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+/* BvhStats printed at src/bvh/build.rs:51 */
+int rt_scene_stats(const rt_scene *scene, rt_bvh_stats *out);
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
+/* nodes: num_inner_nodes entries, tris: num_triangles entries (either may be NULL) */
+int rt_scene_get_flat(const rt_scene *scene, rt_flat_node *nodes, rt_flat_tri *tris);
+
+/* Bvh::build alone, src/bvh/build.rs:45-63, on the host: the same builder
+ * rt_scene_create runs, without touching a GPU.  nodes must hold
+ * num_triangles entries (a binary tree over n leaves has fewer inner nodes),
+ * order num_triangles entries (leaf slot -> mesh triangle id,
+ * object_indices of src/bvh.rs:32).  info->device_bytes is 0.  threads = 0
+ * picks a default. */
+int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                      uint32_t num_triangles, uint32_t threads, rt_flat_node *nodes, uint32_t *order,
+                      rt_scene_info *info, rt_bvh_stats *stats);
+
+/* Bvh::intersect_stream, src/bvh/intersect_stream.rs:10-15: closest hit for n
+ * rays.  hits[i] = mesh triangle id or RT_NO_HIT; rays[i].origin_far[3] is
+ * shrunk to the hit distance.  Accept rule near <= t < far
+ * (src/bvh/intersect_stream.rs:418).  stats may be NULL. */
+int rt_intersect_stream(rt_scene *scene, rt_stream_ray *rays, uint32_t *hits, uint32_t n,
+                        rt_trace_stats *stats);
+int rt_intersect_stream_device(rt_scene *scene, rt_stream_ray *d_rays, uint32_t *d_hits,
+                               uint32_t n, rt_trace_stats *stats, void *hip_stream);
+
+/* Bvh::occluded_stream / Bvh::occluded1, src/bvh/intersect_stream.rs:200-205,
+ * src/bvh/intersect1.rs:7: any hit in [near, far).  occluded[i] = 0/1.  Rays
+ * are not modified. */
+int rt_occluded_stream(rt_scene *scene, const rt_stream_ray *rays, uint8_t *occluded, uint32_t n,
+                       rt_trace_stats *stats);
+int rt_occluded_stream_device(rt_scene *scene, const rt_stream_ray *d_rays, uint8_t *d_occluded,
+                              uint32_t n, rt_trace_stats *stats, void *hip_stream);
+
+/* The integrator call of src/main.rs:133-161 for a whole frame (all tiles of
+ * the shard) instead of one tile: integrate_tile_stream,
+ * src/integrators/integrate_stream.rs:56-164, as generate / extend / shade /
+ * connect kernels over compacted ray queues.  accum is width*height float4
+ * (sum r, sum g, sum b, sum of sample counts; src/main.rs:108); contributions
+ * are ADDED to it.  stats may be NULL. */
+int rt_render(rt_scene *scene, const rt_camera *camera, const rt_light *light,
+              const rt_render_params *params, float *accum, rt_trace_stats *stats);
+int rt_render_device(rt_scene *scene, const rt_camera *camera, const rt_light *light,
+                     const rt_render_params *params, float *d_accum, rt_trace_stats *stats,
+                     void *hip_stream);
+
+/* Primary rays of a frame pass as StreamRays, generate_rays of
+ * src/integrators/integrate_stream.rs:14-54 for every pixel of the frame:
+ * rays[(y*width + x)*samples + s].  Used for per-ray parity checks. */
+int rt_generate_primary(rt_ctx *ctx, const rt_camera *camera, const rt_render_params *params,
+                        rt_stream_ray *rays);
+
+/* color_vec_to_rgb_norm_gamma, src/main.rs:34-41: rgb = sqrt(sum/w)*255 with
+ * Rust's saturating float->u8 cast.  Host buffers. */
+int rt_resolve(rt_ctx *ctx, const float *accum, uint32_t width, uint32_t height, uint8_t *rgb);
+
+/* Duration in milliseconds of the traversal kernels of the most recent trace
+ * or render call on this context, measured with HIP events on the stream the
+ * kernels ran on: [0] closest-hit (extend), [1] any-hit (connect), [2] all
+ * other kernels; launches[k] = number of launches summed into ms[k].  The
+ * events are synchronised by this call. */
+int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,315 @@
+"""Python host binding of librtcore.so, the MI355X ray-tracing core.
+
+Mirrors the reference's trace boundary: `Scene.intersect_stream` /
+`Scene.occluded_stream` stand in for `Bvh::intersect_stream` /
+`Bvh::occluded_stream` (src/bvh/intersect_stream.rs:10-15, 200-205) and
+`Scene.render` for the per-tile integrator call of src/main.rs:133-161.
+
+There is no CPU fallback: importing works without a GPU (so the library's
+symbols can be checked), but every compute call goes to the HIP library and
+raises `RtError` when that fails.  A missing librtcore.so raises at import.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtcore.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rtcore.h")
+
+NO_HIT = 0xFFFFFFFF
+RENDER_VISIT_STATS = 1
+
+RAY_DTYPE = np.dtype([("origin_far", np.float32, 4),
+                      ("dir_recip_near", np.float32, 4),
+                      ("direction", np.float32, 4)])
+NODE_DTYPE = np.dtype([("bx", np.float32, 4), ("by", np.float32, 4), ("bz", np.float32, 4),
+                       ("left", np.uint32), ("right", np.uint32),
+                       ("left_count", np.uint32), ("right_count", np.uint32)])
+TRI_DTYPE = np.dtype([("v0", np.float32, 3), ("v0v1", np.float32, 3), ("v0v2", np.float32, 3),
+                      ("id", np.uint32), ("pad", np.uint32, 2)])
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rtcore error %d: %s" % (code, msg))
+        self.code = code
+
+
+class TraceStats(C.Structure):
+    """src/trace_stats.rs:4-12"""
+    _fields_ = [(n, C.c_uint64) for n in ("total_rays", "inner_visit", "inner_rays", "leaf_visit",
+                                          "leaf_rays", "leaf_objs", "obj_intersect")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class BvhStats(C.Structure):
+    """src/bvh/build.rs:5-11"""
+    _fields_ = [(n, C.c_uint32) for n in ("num_leaves", "num_objs", "max_depth", "max_objs")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("num_triangles", C.c_uint32), ("num_inner_nodes", C.c_uint32),
+                ("root_ref", C.c_uint32), ("root_count", C.c_uint32), ("device_bytes", C.c_uint64)]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("target", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov_deg", C.c_float)]
+
+
+class LightC(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("intensity", C.c_float * 3)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
+                ("sample_offset", C.c_uint32), ("max_bounces", C.c_uint32),
+                ("tile_size", C.c_uint32), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32), ("samples_per_pass", C.c_uint32),
+                ("flags", C.c_uint32), ("seed", C.c_uint64)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "librtcore.so is missing (%s). Build it with `make -C %s/csrc` or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback."
+        % (LIB_PATH, _HERE))
+
+_lib = C.CDLL(LIB_PATH)
+_vp = C.c_void_p
+
+EXPORTS = {
+    "rt_last_error": (C.c_char_p, []),
+    "rt_version": (C.c_char_p, []),
+    "rt_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "rt_ctx_destroy": (None, [_vp]),
+    "rt_ctx_set_max_paths": (C.c_int, [_vp, C.c_uint64]),
+    "rt_ctx_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint32 * 3)]),
+    "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
+    "rt_scene_destroy": (None, [_vp]),
+    "rt_bvh_build_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
+                                    C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
+    "rt_scene_stats": (C.c_int, [_vp, C.POINTER(BvhStats)]),
+    "rt_scene_get_info": (C.c_int, [_vp, C.POINTER(SceneInfo)]),
+    "rt_scene_get_flat": (C.c_int, [_vp, _vp, _vp]),
+    "rt_intersect_stream": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats)]),
+    "rt_intersect_stream_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats), _vp]),
+    "rt_occluded_stream": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats)]),
+    "rt_occluded_stream_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats), _vp]),
+    "rt_render": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(LightC), C.POINTER(RenderParams), _vp,
+                            C.POINTER(TraceStats)]),
+    "rt_render_device": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(LightC), C.POINTER(RenderParams),
+                                   _vp, C.POINTER(TraceStats), _vp]),
+    "rt_generate_primary": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(RenderParams), _vp]),
+    "rt_resolve": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
+}
+for _name, (_res, _args) in EXPORTS.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = the library lacks a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(rc, _lib.rt_last_error().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def camera_c(cam):
+    return CameraC(_f3(cam.eye), _f3(cam.target), _f3(cam.up), float(cam.fov_deg))
+
+
+def light_c(light):
+    return LightC(_f3(light.pos), _f3(light.intensity))
+
+
+def version():
+    return _lib.rt_version().decode()
+
+
+def make_rays(origins, directions, near=0.0, far=np.inf):
+    """StreamRay::new (src/ray.rs:17-24) on arrays."""
+    o = np.asarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.asarray(directions, dtype=np.float32).reshape(-1, 3)
+    rays = np.zeros(o.shape[0], dtype=RAY_DTYPE)
+    rays["origin_far"][:, :3] = o
+    rays["origin_far"][:, 3] = np.float32(far) if np.isscalar(far) else np.asarray(far, np.float32)
+    rays["direction"][:, :3] = d
+    with np.errstate(divide="ignore"):
+        rays["dir_recip_near"][:, :3] = np.float32(1.0) / d
+    rays["dir_recip_near"][:, 3] = np.float32(near) if np.isscalar(near) else np.asarray(near, np.float32)
+    return rays
+
+
+def build_bvh_host(positions, indices, threads=0):
+    """Bvh::build (src/bvh/build.rs:45-63) on the host only; returns
+    (nodes, order, info dict, BvhStats dict)."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    nt = idx.shape[0]
+    nodes = np.zeros(nt, dtype=NODE_DTYPE)
+    order = np.zeros(nt, dtype=np.uint32)
+    info, st = SceneInfo(), BvhStats()
+    _check(_lib.rt_bvh_build_host(_p(pos), pos.shape[0], _p(idx), nt, int(threads), _p(nodes), _p(order),
+                                  C.byref(info), C.byref(st)))
+    inf = {n: int(getattr(info, n)) for n, _ in SceneInfo._fields_}
+    return nodes[:inf["num_inner_nodes"]].copy(), order, inf, st.as_dict()
+
+
+class Context:
+    """One per GPU (rt_ctx)."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        _check(_lib.rt_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.rt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_max_paths(self, n):
+        _check(_lib.rt_ctx_set_max_paths(self.h, int(n)))
+
+    def last_kernel_ms(self):
+        """({extend, connect, other} milliseconds, launches) of the last call."""
+        ms = (C.c_float * 3)()
+        ln = (C.c_uint32 * 3)()
+        _check(_lib.rt_ctx_last_kernel_ms(self.h, C.byref(ms), C.byref(ln)))
+        names = ("extend", "connect", "other")
+        return {n: float(ms[i]) for i, n in enumerate(names)}, {n: int(ln[i]) for i, n in enumerate(names)}
+
+    def generate_primary(self, cam, width, height, samples, tile_size=16, seed=1235468, sample_offset=0):
+        p = RenderParams(width, height, samples, sample_offset, 0, tile_size, 0, 1, 0, 0, seed)
+        rays = np.zeros(width * height * samples, dtype=RAY_DTYPE)
+        cc = camera_c(cam)
+        _check(_lib.rt_generate_primary(self.h, C.byref(cc), C.byref(p), _p(rays)))
+        return rays
+
+    def resolve(self, accum):
+        a = np.ascontiguousarray(accum, dtype=np.float32)
+        h, w = a.shape[:2]
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        _check(_lib.rt_resolve(self.h, _p(a), w, h, _p(rgb)))
+        return rgb
+
+
+class Scene:
+    """Device-resident BVH + triangles (rt_scene); the `Bvh` of src/bvh.rs:30-34."""
+
+    def __init__(self, ctx, positions, indices, geom_normals):
+        self.ctx = ctx
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        nrm = np.ascontiguousarray(geom_normals, dtype=np.float32)
+        if pos.ndim != 2 or pos.shape[1] != 3 or idx.ndim != 2 or idx.shape[1] != 3 or nrm.shape != idx.shape:
+            raise ValueError("positions [nv,3], indices [nt,3], geom_normals [nt,3] expected")
+        h = _vp()
+        _check(_lib.rt_scene_create(ctx.h, _p(pos), pos.shape[0], _p(idx), idx.shape[0], _p(nrm), C.byref(h)))
+        self.h = h
+        self.num_triangles = idx.shape[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.rt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bvh_stats(self):
+        st = BvhStats()
+        _check(_lib.rt_scene_stats(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def info(self):
+        i = SceneInfo()
+        _check(_lib.rt_scene_get_info(self.h, C.byref(i)))
+        return {n: int(getattr(i, n)) for n, _ in SceneInfo._fields_}
+
+    def flatten(self):
+        inf = self.info()
+        nodes = np.zeros(inf["num_inner_nodes"], dtype=NODE_DTYPE)
+        tris = np.zeros(inf["num_triangles"], dtype=TRI_DTYPE)
+        _check(_lib.rt_scene_get_flat(self.h, _p(nodes), _p(tris)))
+        return nodes, tris
+
+    # -- host-buffer trace calls ------------------------------------------------
+    def intersect_stream(self, rays, stats=True):
+        """Returns (hit ids u32, hit distances f32, stats dict or None); `rays` is not modified."""
+        r = np.ascontiguousarray(rays.copy())
+        hits = np.full(r.shape[0], NO_HIT, dtype=np.uint32)
+        st = TraceStats()
+        _check(_lib.rt_intersect_stream(self.h, _p(r), _p(hits), r.shape[0], C.byref(st) if stats else None))
+        return hits, r["origin_far"][:, 3].copy(), (st.as_dict() if stats else None)
+
+    def occluded_stream(self, rays, stats=True):
+        r = np.ascontiguousarray(rays)
+        occ = np.zeros(r.shape[0], dtype=np.uint8)
+        st = TraceStats()
+        _check(_lib.rt_occluded_stream(self.h, _p(r), _p(occ), r.shape[0], C.byref(st) if stats else None))
+        return occ, (st.as_dict() if stats else None)
+
+    def render(self, cam, light, width, height, samples, max_bounces=2, tile_size=16, seed=1235468,
+               sample_offset=0, shard_index=0, shard_count=1, samples_per_pass=0, accum=None,
+               visit_stats=False):
+        if accum is None:
+            accum = np.zeros((height, width, 4), dtype=np.float32)
+        assert accum.dtype == np.float32 and accum.flags["C_CONTIGUOUS"] and accum.shape == (height, width, 4)
+        p = RenderParams(width, height, samples, sample_offset, max_bounces, tile_size, shard_index,
+                         shard_count, samples_per_pass, RENDER_VISIT_STATS if visit_stats else 0, seed)
+        st = TraceStats()
+        cc, lc = camera_c(cam), light_c(light)
+        _check(_lib.rt_render(self.h, C.byref(cc), C.byref(lc), C.byref(p), _p(accum), C.byref(st)))
+        return accum, st.as_dict()
+
+    # -- device-pointer calls (inputs resident in HBM) --------------------------
+    def intersect_stream_device(self, rays_ptr, hits_ptr, n, stream=0, stats=False):
+        st = TraceStats()
+        _check(_lib.rt_intersect_stream_device(self.h, _vp(rays_ptr), _vp(hits_ptr), int(n),
+                                               C.byref(st) if stats else None, _vp(stream)))
+        return st.as_dict() if stats else None
+
+    def occluded_stream_device(self, rays_ptr, occ_ptr, n, stream=0, stats=False):
+        st = TraceStats()
+        _check(_lib.rt_occluded_stream_device(self.h, _vp(rays_ptr), _vp(occ_ptr), int(n),
+                                              C.byref(st) if stats else None, _vp(stream)))
+        return st.as_dict() if stats else None
+
+    def render_device(self, cam, light, accum_ptr, width, height, samples, max_bounces=2, tile_size=16,
+                      seed=1235468, sample_offset=0, shard_index=0, shard_count=1, samples_per_pass=0,
+                      stream=0, stats=True, visit_stats=False):
+        p = RenderParams(width, height, samples, sample_offset, max_bounces, tile_size, shard_index,
+                         shard_count, samples_per_pass, RENDER_VISIT_STATS if visit_stats else 0, seed)
+        st = TraceStats()
+        cc, lc = camera_c(cam), light_c(light)
+        _check(_lib.rt_render_device(self.h, C.byref(cc), C.byref(lc), C.byref(p), _vp(accum_ptr),
+                                     C.byref(st) if stats else None, _vp(stream)))
+        return st.as_dict() if stats else None

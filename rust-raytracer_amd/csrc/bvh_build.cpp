@@ -1,0 +1,354 @@
+// Host-side binned-SAH BVH builder (see bvh_build.hpp).
+//
+// Follows src/bvh/build.rs:65-207 decision for decision so the resulting tree
+// (and therefore every hit id, tie and visit counter) is the reference's:
+//   - leaf iff 1..8 triangles, or zero centroid extent         (80-81, 93-101)
+//   - axis: x if sx>sy && sx>sz, else y if sy>sz, else z        (103-109)
+//   - bucket = (k1*(c-k0)) as usize, k1 = 8*(1-0.01)/extent     (114-118)
+//   - 7 candidate splits, cost=(SA_l*n_l+SA_r*n_r)/SA, strict < (132-150)
+//   - Hoare partition on bucket <= min_bucket                   (152-168)
+//   - child boxes are the unions of the bucket boxes            (147-148)
+// All arithmetic is f32 and un-fused (this file is built with
+// -ffp-contract=off).  The recursion of the reference is replaced by an explicit
+// work stack that emits nodes in pre-order; large inputs are cut into
+// independent subtrees that are built on several threads and spliced.
+#include "bvh_build.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <limits>
+#include <thread>
+
+namespace rtc {
+namespace {
+
+constexpr int kBuckets = 8;
+constexpr uint32_t kLeaf = 0x80000000u;
+constexpr uint32_t kTaskTag = 0x40000000u; // placeholder ref: deferred subtree (top phase only)
+
+struct Box {
+    float lo[3], hi[3];
+    void clear()
+    {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::numeric_limits<float>::infinity();
+            hi[a] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void add_point(const float *p)
+    {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = lo[a] < p[a] ? lo[a] : p[a];
+            hi[a] = hi[a] > p[a] ? hi[a] : p[a];
+        }
+    }
+    void add_box(const Box &b)
+    {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = lo[a] < b.lo[a] ? lo[a] : b.lo[a];
+            hi[a] = hi[a] > b.hi[a] ? hi[a] : b.hi[a];
+        }
+    }
+    float area() const // src/aabb.rs:37-40
+    {
+        float sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+        return 2.f * ((sx * sy + sx * sz) + sy * sz);
+    }
+};
+
+struct Prim {
+    float c[3]; // centroid, src/mesh.rs:107-110
+    Box box;    // src/mesh.rs:97-104
+};
+
+inline uint32_t bucket_of(float k0, float k1, float c)
+{
+    float f = k1 * (c - k0);
+    if (!(f > 0.f)) return 0; // Rust `as usize`: negative and NaN -> 0
+    if (f >= 4294967296.f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+struct Work {
+    uint32_t begin, end; // range in the order array
+    uint32_t depth;
+    uint32_t parent;     // node index in `nodes` receiving the child ref, or ~0u for the root
+    uint32_t side;       // 0 = left, 1 = right
+};
+
+struct Deferred {
+    uint32_t begin, end, depth;
+};
+
+struct Emit {
+    std::vector<rt_flat_node> nodes;
+    rt_bvh_stats stats{};
+    uint32_t root_ref = 0, root_count = 0;
+    // top phase only: pre-order sequence of events; value = node index, or
+    // kTaskTag | task index.
+    std::vector<uint32_t> events;
+};
+
+inline void set_child(Emit &e, const Work &w, uint32_t ref, uint32_t count)
+{
+    if (w.parent == ~0u) {
+        e.root_ref = ref;
+        e.root_count = count;
+    } else if (w.side == 0) {
+        e.nodes[w.parent].left = ref;
+        e.nodes[w.parent].left_count = count;
+    } else {
+        e.nodes[w.parent].right = ref;
+        e.nodes[w.parent].right_count = count;
+    }
+}
+
+// Builds the subtree over order[begin,end).  With `defer` non-null, ranges of
+// at most `grain` triangles (but more than a leaf) are not expanded; they are
+// recorded as tasks.
+void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t end, uint32_t depth,
+                 Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events)
+{
+    std::vector<Work> stack;
+    stack.push_back({begin, end, depth, ~0u, 0});
+    while (!stack.empty()) {
+        Work w = stack.back();
+        stack.pop_back();
+        uint32_t n = w.end - w.begin;
+
+        bool leaf = (n >= 1 && n <= 8);
+        Box bounds, cb;
+        float size[3] = {0, 0, 0};
+        if (!leaf) {
+            if (defer && n <= grain) {
+                uint32_t t = (uint32_t)defer->size();
+                defer->push_back({w.begin, w.end, w.depth});
+                set_child(e, w, kTaskTag | t, 0);
+                if (track_events) e.events.push_back(kTaskTag | t);
+                continue;
+            }
+            bounds.clear();
+            cb.clear();
+            for (uint32_t i = w.begin; i < w.end; i++) {
+                const Prim &p = prims[order[i]];
+                bounds.add_box(p.box);
+                cb.add_point(p.c);
+            }
+            for (int a = 0; a < 3; a++) size[a] = cb.hi[a] - cb.lo[a];
+            float nsq = (size[0] * size[0] + size[1] * size[1]) + size[2] * size[2];
+            if (nsq == 0.f) leaf = true;
+        }
+        if (leaf) {
+            set_child(e, w, kLeaf | w.begin, n);
+            e.stats.num_leaves += 1;
+            e.stats.num_objs += n;
+            e.stats.max_depth = std::max(e.stats.max_depth, w.depth);
+            e.stats.max_objs = std::max(e.stats.max_objs, n);
+            continue;
+        }
+
+        int axis = (size[0] > size[1] && size[0] > size[2]) ? 0 : (size[1] > size[2] ? 1 : 2);
+        float k0 = cb.lo[axis];
+        float k1 = (float)kBuckets * (1.f - 0.01f) / (cb.hi[axis] - cb.lo[axis]);
+
+        Box bbox[kBuckets];
+        uint32_t bcnt[kBuckets];
+        for (int b = 0; b < kBuckets; b++) {
+            bbox[b].clear();
+            bcnt[b] = 0;
+        }
+        for (uint32_t i = w.begin; i < w.end; i++) {
+            const Prim &p = prims[order[i]];
+            uint32_t b = bucket_of(k0, k1, p.c[axis]);
+            bbox[b].add_box(p.box);
+            bcnt[b] += 1;
+        }
+
+        // prefix / suffix unions (min/max are exact, so the fold order of the
+        // reference's per-candidate folds does not matter)
+        Box pre[kBuckets], suf[kBuckets];
+        uint32_t pcnt[kBuckets], scnt[kBuckets];
+        pre[0] = bbox[0];
+        pcnt[0] = bcnt[0];
+        for (int b = 1; b < kBuckets; b++) {
+            pre[b] = pre[b - 1];
+            pre[b].add_box(bbox[b]);
+            pcnt[b] = pcnt[b - 1] + bcnt[b];
+        }
+        suf[kBuckets - 1] = bbox[kBuckets - 1];
+        scnt[kBuckets - 1] = bcnt[kBuckets - 1];
+        for (int b = kBuckets - 2; b >= 0; b--) {
+            suf[b] = suf[b + 1];
+            suf[b].add_box(bbox[b]);
+            scnt[b] = scnt[b + 1] + bcnt[b];
+        }
+
+        uint32_t min_bucket = 0;
+        float min_cost = std::numeric_limits<float>::infinity();
+        Box bl, br;
+        bl.clear();
+        br.clear();
+        float parent_area = bounds.area();
+        for (int i = 0; i < kBuckets - 1; i++) {
+            float cost =
+                (pre[i].area() * (float)pcnt[i] + suf[i + 1].area() * (float)scnt[i + 1]) / parent_area;
+            if (cost < min_cost) {
+                min_bucket = (uint32_t)i;
+                min_cost = cost;
+                bl = pre[i];
+                br = suf[i + 1];
+            }
+        }
+
+        uint32_t *idx = order + w.begin;
+        uint32_t left = 0, right = n - 1;
+        for (;;) {
+            while (bucket_of(k0, k1, prims[idx[left]].c[axis]) <= min_bucket) left++;
+            while (bucket_of(k0, k1, prims[idx[right]].c[axis]) > min_bucket) right--;
+            if (left >= right) break;
+            std::swap(idx[left], idx[right]);
+        }
+        uint32_t split = left;
+
+        uint32_t me = (uint32_t)e.nodes.size();
+        rt_flat_node nd{};
+        for (int a = 0; a < 3; a++) {
+            float *dst = a == 0 ? nd.bx : (a == 1 ? nd.by : nd.bz);
+            dst[0] = bl.lo[a];
+            dst[1] = br.lo[a];
+            dst[2] = bl.hi[a];
+            dst[3] = br.hi[a];
+        }
+        e.nodes.push_back(nd);
+        if (track_events) e.events.push_back(me);
+        set_child(e, w, me, 0);
+        // right first so that the left subtree is emitted next (pre-order)
+        stack.push_back({w.begin + split, w.end, w.depth + 1, me, 1});
+        stack.push_back({w.begin, w.begin + split, w.depth + 1, me, 0});
+    }
+}
+
+void merge_stats(rt_bvh_stats &a, const rt_bvh_stats &b) // src/bvh/build.rs:35-42
+{
+    a.num_leaves += b.num_leaves;
+    a.num_objs += b.num_objs;
+    a.max_depth = std::max(a.max_depth, b.max_depth);
+    a.max_objs = std::max(a.max_objs, b.max_objs);
+}
+
+} // namespace
+
+void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uint32_t nt,
+               unsigned threads, HostBvh &out)
+{
+    (void)nv;
+    std::vector<Prim> prims(nt);
+    out.order.resize(nt);
+    auto fill = [&](uint32_t t0, uint32_t t1) {
+        for (uint32_t t = t0; t < t1; t++) {
+            const float *a = positions + 3 * (size_t)indices[3 * (size_t)t + 0];
+            const float *b = positions + 3 * (size_t)indices[3 * (size_t)t + 1];
+            const float *c = positions + 3 * (size_t)indices[3 * (size_t)t + 2];
+            Prim &p = prims[t];
+            for (int k = 0; k < 3; k++) p.c[k] = ((a[k] + b[k]) + c[k]) / 3.f;
+            p.box.clear();
+            p.box.add_point(a);
+            p.box.add_point(b);
+            p.box.add_point(c);
+            out.order[t] = t;
+        }
+    };
+    if (threads < 1) threads = 1;
+    if (threads == 1 || nt < 200000) {
+        fill(0, nt);
+        Emit e;
+        build_range(prims.data(), out.order.data(), 0, nt, 0, e, nullptr, 0, false);
+        out.nodes.swap(e.nodes);
+        out.root_ref = e.root_ref;
+        out.root_count = e.root_count;
+        out.stats = e.stats;
+        return;
+    }
+
+    {
+        std::vector<std::thread> pool;
+        uint32_t per = (nt + threads - 1) / threads;
+        for (unsigned i = 0; i < threads; i++) {
+            uint32_t t0 = std::min(nt, i * per), t1 = std::min(nt, (i + 1) * per);
+            pool.emplace_back(fill, t0, t1);
+        }
+        for (auto &t : pool) t.join();
+    }
+
+    // top phase: expand until ranges are small, remember the rest as tasks
+    Emit top;
+    std::vector<Deferred> tasks;
+    uint32_t grain = std::max<uint32_t>(4096, nt / (threads * 16));
+    build_range(prims.data(), out.order.data(), 0, nt, 0, top, &tasks, grain, true);
+
+    // parallel phase: every task builds its subtree with local node indices
+    std::vector<Emit> sub(tasks.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= tasks.size()) break;
+            build_range(prims.data(), out.order.data(), tasks[i].begin, tasks[i].end, tasks[i].depth,
+                        sub[i], nullptr, 0, false);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < threads; i++) pool.emplace_back(worker);
+        for (auto &t : pool) t.join();
+    }
+
+    // splice in pre-order
+    std::vector<uint32_t> top_final(top.nodes.size()), task_base(tasks.size());
+    uint32_t counter = 0;
+    for (uint32_t ev : top.events) {
+        if (ev & kTaskTag) {
+            uint32_t t = ev & ~kTaskTag;
+            task_base[t] = counter;
+            counter += (uint32_t)sub[t].nodes.size();
+        } else {
+            top_final[ev] = counter++;
+        }
+    }
+    out.nodes.assign(counter, rt_flat_node{});
+    auto map_top_ref = [&](uint32_t ref, uint32_t &count) -> uint32_t {
+        if (ref & kLeaf) return ref;
+        if (ref & kTaskTag) {
+            uint32_t t = ref & ~kTaskTag;
+            if (sub[t].root_ref & kLeaf) { // cannot happen (tasks hold > 8 triangles) unless degenerate
+                count = sub[t].root_count;
+                return sub[t].root_ref;
+            }
+            return task_base[t] + sub[t].root_ref;
+        }
+        return top_final[ref];
+    };
+    for (size_t i = 0; i < top.nodes.size(); i++) {
+        rt_flat_node nd = top.nodes[i];
+        nd.left = map_top_ref(nd.left, nd.left_count);
+        nd.right = map_top_ref(nd.right, nd.right_count);
+        out.nodes[top_final[i]] = nd;
+    }
+    for (size_t t = 0; t < tasks.size(); t++) {
+        uint32_t base = task_base[t];
+        for (size_t i = 0; i < sub[t].nodes.size(); i++) {
+            rt_flat_node nd = sub[t].nodes[i];
+            if (!(nd.left & kLeaf)) nd.left += base;
+            if (!(nd.right & kLeaf)) nd.right += base;
+            out.nodes[base + i] = nd;
+        }
+        merge_stats(top.stats, sub[t].stats);
+    }
+    out.stats = top.stats;
+    uint32_t rc = top.root_count;
+    out.root_ref = map_top_ref(top.root_ref, rc);
+    out.root_count = rc;
+}
+
+} // namespace rtc

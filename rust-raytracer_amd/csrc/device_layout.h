@@ -1,0 +1,97 @@
+// Device-side data layout of the ray-tracing core (gfx950).
+//
+// Everything here is uploaded once per scene and then only read.
+#pragma once
+
+#include <stdint.h>
+
+namespace rtc {
+
+// Child reference as stored in device nodes and on traversal stacks.
+//   bit 31 clear : index of an inner node
+//   bit 31 set   : leaf.  bit 30 clear: bits 3..29 = first slot in the
+//                  leaf-ordered triangle array, bits 0..2 = count-1 (count 1..8,
+//                  the reference's leaf rule, src/bvh/build.rs:80-81).
+//                  bit 30 set: low 30 bits index `big_leaves` {first,count}
+//                  (leaves made by the zero-centroid-extent rule,
+//                  src/bvh/build.rs:93-101, can hold any number of triangles).
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kBigLeafBit = 0x40000000u;
+constexpr uint32_t kMaxPackedFirst = 1u << 27;
+constexpr uint32_t kDone = 0xFFFFFFFFu; // traversal sentinel (never a valid ref)
+
+// 64-byte inner node: both children's boxes in the reference's lane order
+// {minL, minR, maxL, maxR} per axis (src/bvh.rs:19-23) + two child refs.
+struct alignas(64) DevNode {
+    float bx[4];
+    float by[4];
+    float bz[4];
+    uint32_t left;
+    uint32_t right;
+    uint32_t pad0;
+    uint32_t pad1;
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+
+// 48-byte triangle in leaf order: TriangleOpt {v0v1, v0v2, v0}
+// (src/triangle_opt.rs:10-14) read as three float4, with the mesh triangle id
+// (object_indices, src/bvh.rs:32) in the spare lanes.
+struct alignas(16) DevTri {
+    float v0[3];
+    float e1[3]; // v0v1
+    float e2[3]; // v0v2
+    uint32_t id;
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevTri) == 48, "DevTri must be 48 bytes");
+
+struct BigLeaf {
+    uint32_t first;
+    uint32_t count;
+};
+
+// Internal queue ray (32 bytes): the reciprocal direction of StreamRay
+// (src/ray.rs:17-24) is recomputed in the kernel by the same IEEE division.
+struct alignas(16) QRay {
+    float o[3];
+    float near_t;
+    float d[3];
+    float far_t;
+};
+static_assert(sizeof(QRay) == 32, "QRay must be 32 bytes");
+
+// PathInfo of src/integrators/common.rs:14-19 plus the keys of the
+// counter-based random numbers and the slot that owns the path's radiance.
+struct alignas(16) PathInfo {
+    float w[3];
+    uint32_t slot;   // index into the pass's radiance arrays
+    uint32_t pixel;  // global pixel index  y*width + x
+    uint32_t sample; // global sample index
+    uint32_t bounces;
+    uint32_t pad;
+};
+static_assert(sizeof(PathInfo) == 32, "PathInfo must be 32 bytes");
+
+struct alignas(16) ShadowInfo {
+    float w[3]; // path weight * light weight
+    uint32_t slot;
+};
+
+struct SceneDev {
+    const DevNode *nodes;
+    const DevTri *tris;
+    const BigLeaf *big_leaves;
+    const float *normals; // float4 per mesh triangle (xyz, 0)
+    uint32_t root_ref;
+    uint32_t max_depth;
+};
+
+// Counters of src/trace_stats.rs:4-12 as kept on the device.
+struct StatsDev {
+    unsigned long long total_rays;
+    unsigned long long inner_rays;
+    unsigned long long leaf_rays;
+    unsigned long long obj_intersect;
+};
+
+} // namespace rtc

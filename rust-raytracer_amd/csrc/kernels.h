@@ -1,0 +1,87 @@
+// Launch interface between the C-ABI layer (rtcore.hip) and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+
+#ifndef RTC_TRACE_BLOCK
+#define RTC_TRACE_BLOCK 256
+#endif
+#ifndef RTC_LDS_STACK_DEPTH
+#define RTC_LDS_STACK_DEPTH 24
+#endif
+
+namespace rtc {
+
+// StreamRay (src/ray.rs:6-12) as three float4.
+struct alignas(16) rt_stream_ray_dev {
+    float4 origin_far;
+    float4 dir_recip_near;
+    float4 direction;
+};
+
+// Camera frame derived on the host (src/camera.rs:25-37, 63-75).
+struct CameraDev {
+    float eye[3];
+    float right[3];
+    float up[3];
+    float top_left[3];
+    float step_x[3];
+    float step_y[3];
+    float pixel_size;
+};
+
+// One render pass: a contiguous run of the shard's tiles times up to
+// samples_per_pass samples.
+struct PassDev {
+    uint32_t width, height;
+    uint32_t tile_size, tiles_x;
+    uint32_t shard_index, shard_count;
+    uint32_t tile_begin, tile_count; // in the shard's own tile numbering
+    uint32_t samples_per_pass;       // slot stride per pixel
+    uint32_t samples_this_pass;      // <= samples_per_pass
+    uint32_t sample_base;            // global index of sample 0 of this pass
+    uint32_t num_slots;              // tile_count * tile_size^2 * samples_per_pass
+    uint32_t seed_key;
+};
+
+struct ShadeArgs {
+    const QRay *rays_in;
+    const PathInfo *infos_in;
+    const uint32_t *hit_ids;
+    const uint32_t *n_in;
+    const float *normals;
+    QRay *rays_out;
+    PathInfo *infos_out;
+    uint32_t *n_out;
+    QRay *shadow_rays;
+    ShadowInfo *shadow_infos;
+    uint32_t *n_shadow;
+    float light_pos[3];
+    float light_intensity[3];
+    uint32_t max_bounces;
+    uint32_t seed_key;
+};
+
+void launch_trace_stream(bool anyhit, bool stats, const SceneDev &sc, rt_stream_ray_dev *rays, unsigned *hits,
+                         unsigned char *occluded, unsigned n, unsigned *ovf, StatsDev *dstats,
+                         unsigned max_blocks, hipStream_t stream);
+void launch_extend(bool stats, const SceneDev &sc, QRay *rays, unsigned *hit_ids, const unsigned *n_ptr,
+                   unsigned n_upper, unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream);
+void launch_connect(bool stats, const SceneDev &sc, const QRay *rays, const ShadowInfo *infos,
+                    const unsigned *n_ptr, unsigned n_upper, float *rad_r, float *rad_g, float *rad_b,
+                    unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream);
+void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream);
+void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,
+                     float *rad_r, float *rad_g, float *rad_b, hipStream_t stream);
+void launch_generate_stream(const CameraDev &cam, const PassDev &ps, rt_stream_ray_dev *rays,
+                            unsigned long long total, hipStream_t stream);
+void launch_shade(const ShadeArgs &a, unsigned n_upper, hipStream_t stream);
+void launch_accumulate(const PassDev &ps, const float *rad_r, const float *rad_g, const float *rad_b,
+                       float *accum, hipStream_t stream);
+void launch_resolve(const float *accum, unsigned long long npix, unsigned char *rgb, hipStream_t stream);
+int trace_blocks_per_cu();
+
+} // namespace rtc

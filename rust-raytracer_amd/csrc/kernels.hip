@@ -1,0 +1,828 @@
+// HIP kernels of the MI355X ray-tracing core (gfx950, wave64).
+//
+//   extend   : closest-hit BVH traversal          <- Bvh::intersect_stream
+//   connect  : any-hit traversal + radiance add   <- Bvh::occluded1 / occluded_stream
+//   generate : camera rays                        <- generate_rays
+//   shade    : NEE shadow ray + diffuse bounce    <- integrate_tile_stream loop body
+//   accumulate / resolve                          <- pixel accumulation, tonemap
+//
+// Arithmetic rules (this file is compiled with -ffp-contract=off): every f32
+// operation is un-fused and in the reference's order, except the node slab
+// test, which uses one fused multiply-subtract per plane exactly where the
+// reference calls fused_mul_sub (src/bvh/intersect1.rs:159-164,
+// src/bvh/intersect_stream.rs:123-128).  Division and sqrt are the correctly
+// rounded ones (hipcc default).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+#include "kernels.h"
+
+namespace rtc {
+
+// ------------------------------------------------------------------------
+// small helpers
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 mul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 divs(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// nalgebra: dot = (ax*bx + ay*by) + az*bz, cross as below, all un-fused
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 normalize(V3 a) { return divs(a, sqrtf(dot(a, a))); }
+
+__device__ __forceinline__ unsigned lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` below the calling lane
+__device__ __forceinline__ unsigned prefix_count(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Wave-aggregated queue append: one atomic per wave.  Returns the slot of the
+// calling lane (valid only where pred is true).
+__device__ __forceinline__ unsigned queue_reserve(bool pred, unsigned *counter)
+{
+    unsigned long long mask = __ballot(pred);
+    unsigned total = (unsigned)__popcll(mask);
+    unsigned base = 0;
+    if (total != 0) {
+        unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+        if (lane_id() == leader) base = atomicAdd(counter, total);
+        base = (unsigned)__shfl((int)base, (int)leader);
+    }
+    return base + prefix_count(mask);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------------
+// traversal core
+
+struct RayRegs {
+    V3 o, d, rd;   // origin, direction, 1/direction
+    float near_t;  // dir_recip_near.w
+    float far_t;   // origin_far.w, shrinks on closest-hit
+};
+
+struct Counters {
+    unsigned inner, leaf, tris;
+};
+
+// Per-lane traversal stack: the first kLdsDepth entries live in LDS in
+// [entry][thread] order (lane l and lane l+32 hit the same bank in different
+// halves of a ds_read_b32, so accesses are conflict-free); deeper entries go to
+// a global overflow area laid out the same way.
+template <int BLOCK, int LDS_DEPTH>
+struct Stack {
+    unsigned *lds;      // &shared[threadIdx.x]
+    unsigned *ovf;      // &overflow[global thread]
+    unsigned ovf_stride; // threads in the grid
+    int sp;
+    __device__ __forceinline__ void push(unsigned v)
+    {
+        if (sp < LDS_DEPTH)
+            lds[sp * BLOCK] = v;
+        else
+            ovf[(size_t)(sp - LDS_DEPTH) * ovf_stride] = v;
+        sp++;
+    }
+    __device__ __forceinline__ unsigned pop()
+    {
+        sp--;
+        if (sp < LDS_DEPTH) return lds[sp * BLOCK];
+        return ovf[(size_t)(sp - LDS_DEPTH) * ovf_stride];
+    }
+};
+
+// Moeller-Trumbore of src/triangle_opt.rs:19-42: no back-face cull, |det| <
+// f32::EPSILON rejected, u in [0,1], v >= 0, u+v <= 1; returns t or +inf.
+__device__ __forceinline__ float tri_test(const float4 t0, const float4 t1, const float4 t2, V3 o, V3 d)
+{
+    V3 v0 = v3(t0.x, t0.y, t0.z);
+    V3 e1 = v3(t0.w, t1.x, t1.y);
+    V3 e2 = v3(t1.z, t1.w, t2.x);
+    V3 pvec = cross(d, e1);
+    float det = dot(e2, pvec);
+    float inv_det = 1.f / det;
+    V3 tvec = o - v0;
+    float u = dot(tvec, pvec) * inv_det;
+    V3 qvec = cross(tvec, e2);
+    float v = dot(d, qvec) * inv_det;
+    float t = dot(e1, qvec) * inv_det;
+    bool ok = (fabsf(det) >= 1.1920929e-7f) && (u >= 0.f) && (u <= 1.f) && (v >= 0.f) && (u + v <= 1.f);
+    return ok ? t : __builtin_inff();
+}
+
+// One ray through the tree.
+//
+// ANYHIT = false: Bvh::intersect_stream seen from one ray
+// (src/bvh/intersect_stream.rs:67-181): at an inner node both children are
+// tested against [near, current far]; the child with the smaller entry
+// distance (left on ties, nearL <= nearR) is descended first and the other is
+// deferred without a re-test; triangles are accepted for near <= t < far and
+// shrink far (418-422).
+//
+// ANYHIT = true: Bvh::occluded1 (src/bvh/intersect1.rs:7-106): left child
+// first, far fixed, return at the first accepted triangle.
+//
+// NaN: bb*inf - o*inf can be NaN.  v_max_f32 / v_min_f32 ignore a NaN operand,
+// which drops that slab constraint (more visits, never a missed hit), like the
+// reference's operand order does on x86.
+template <bool ANYHIT, bool STATS, class STACK>
+__device__ __forceinline__ unsigned trace_ray(const SceneDev &sc, RayRegs &r, STACK &st, Counters &cnt)
+{
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+
+    const bool negx = (__float_as_uint(r.rd.x) >> 31) != 0;
+    const bool negy = (__float_as_uint(r.rd.y) >> 31) != 0;
+    const bool negz = (__float_as_uint(r.rd.z) >> 31) != 0;
+    const float ordx = r.o.x * r.rd.x, ordy = r.o.y * r.rd.y, ordz = r.o.z * r.rd.z;
+
+    unsigned hit = 0xFFFFFFFFu;
+    unsigned cur = sc.root_ref;
+    st.sp = 0;
+
+    while (true) {
+        // ---- inner nodes
+        while (!(cur & kLeafBit)) {
+            const float4 bx = nodes[(size_t)cur * 4 + 0];
+            const float4 by = nodes[(size_t)cur * 4 + 1];
+            const float4 bz = nodes[(size_t)cur * 4 + 2];
+            const float4 lk = nodes[(size_t)cur * 4 + 3];
+            if (STATS) cnt.inner++;
+            // near/far plane per child, picked by the sign bit of 1/d
+            const float nxl = negx ? bx.z : bx.x, nxr = negx ? bx.w : bx.y;
+            const float fxl = negx ? bx.x : bx.z, fxr = negx ? bx.y : bx.w;
+            const float nyl = negy ? by.z : by.x, nyr = negy ? by.w : by.y;
+            const float fyl = negy ? by.x : by.z, fyr = negy ? by.y : by.w;
+            const float nzl = negz ? bz.z : bz.x, nzr = negz ? bz.w : bz.y;
+            const float fzl = negz ? bz.x : bz.z, fzr = negz ? bz.y : bz.w;
+            const float tnxl = __fmaf_rn(nxl, r.rd.x, -ordx), tnxr = __fmaf_rn(nxr, r.rd.x, -ordx);
+            const float tfxl = __fmaf_rn(fxl, r.rd.x, -ordx), tfxr = __fmaf_rn(fxr, r.rd.x, -ordx);
+            const float tnyl = __fmaf_rn(nyl, r.rd.y, -ordy), tnyr = __fmaf_rn(nyr, r.rd.y, -ordy);
+            const float tfyl = __fmaf_rn(fyl, r.rd.y, -ordy), tfyr = __fmaf_rn(fyr, r.rd.y, -ordy);
+            const float tnzl = __fmaf_rn(nzl, r.rd.z, -ordz), tnzr = __fmaf_rn(nzr, r.rd.z, -ordz);
+            const float tfzl = __fmaf_rn(fzl, r.rd.z, -ordz), tfzr = __fmaf_rn(fzr, r.rd.z, -ordz);
+            const float nearl = fmaxf(fmaxf(fmaxf(tnxl, tnyl), tnzl), r.near_t);
+            const float nearr = fmaxf(fmaxf(fmaxf(tnxr, tnyr), tnzr), r.near_t);
+            const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), r.far_t);
+            const float farr = fminf(fminf(fminf(tfxr, tfyr), tfzr), r.far_t);
+            const bool hl = nearl <= farl;
+            const bool hr = nearr <= farr;
+            const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
+            const bool left_first = ANYHIT ? true : (nearl <= nearr);
+            const unsigned first = left_first ? left : right;
+            const unsigned second = left_first ? right : left;
+            const bool hf = left_first ? hl : hr;
+            const bool hs = left_first ? hr : hl;
+            if (hf) {
+                cur = first;
+                if (hs) st.push(second);
+            } else if (hs) {
+                cur = second;
+            } else {
+                cur = st.sp ? st.pop() : kDone;
+            }
+        }
+        if (cur == kDone) break;
+
+        // ---- leaf
+        unsigned first, count;
+        if (cur & kBigLeafBit) {
+            const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
+            first = bl.first;
+            count = bl.count;
+        } else {
+            first = (cur >> 3) & (kMaxPackedFirst - 1u);
+            count = (cur & 7u) + 1u;
+        }
+        if (STATS) {
+            cnt.leaf++;
+            cnt.tris += count;
+        }
+        bool done = false;
+        for (unsigned i = 0; i < count; i++) {
+            const size_t base = (size_t)(first + i) * 3;
+            const float4 t0 = tris[base + 0];
+            const float4 t1 = tris[base + 1];
+            const float4 t2 = tris[base + 2];
+            const float t = tri_test(t0, t1, t2, r.o, r.d);
+            if (t >= r.near_t && t < r.far_t) {
+                if (ANYHIT) {
+                    hit = 1u;
+                    done = true;
+                    break;
+                }
+                r.far_t = t;
+                hit = __float_as_uint(t2.y);
+            }
+        }
+        if (done) break;
+        cur = st.sp ? st.pop() : kDone;
+        if (cur == kDone) break;
+    }
+    return hit;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_stats(const Counters &cnt, unsigned long long rays, StatsDev *stats)
+{
+    if (!STATS) return;
+    unsigned long long a = wave_sum(cnt.inner), b = wave_sum(cnt.leaf), c = wave_sum(cnt.tris),
+                       d = wave_sum(rays);
+    if (lane_id() == 0) {
+        atomicAdd(&stats->inner_rays, a);
+        atomicAdd(&stats->leaf_rays, b);
+        atomicAdd(&stats->obj_intersect, c);
+        atomicAdd(&stats->total_rays, d);
+    }
+}
+
+constexpr int kBlock = RTC_TRACE_BLOCK;
+constexpr int kLdsDepth = RTC_LDS_STACK_DEPTH;
+
+// ------------------------------------------------------------------------
+// extend / occluded on StreamRay arrays (the drop-in trace boundary)
+
+template <bool ANYHIT, bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_stream_kernel(SceneDev sc, rt_stream_ray_dev *rays,
+                                                             unsigned *hits, unsigned char *occluded,
+                                                             unsigned n, unsigned *ovf, StatsDev *stats)
+{
+    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
+    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned nthreads = gridDim.x * kBlock;
+    Stack<kBlock, kLdsDepth> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.ovf = ovf + gtid;
+    st.ovf_stride = nthreads;
+    Counters cnt{0, 0, 0};
+    unsigned long long nrays = 0;
+    for (unsigned i = gtid; i < n; i += nthreads) {
+        const float4 of = rays[i].origin_far;
+        const float4 rn = rays[i].dir_recip_near;
+        const float4 dd = rays[i].direction;
+        RayRegs r;
+        r.o = v3(of.x, of.y, of.z);
+        r.far_t = of.w;
+        r.rd = v3(rn.x, rn.y, rn.z);
+        r.near_t = rn.w;
+        r.d = v3(dd.x, dd.y, dd.z);
+        const unsigned h = trace_ray<ANYHIT, STATS>(sc, r, st, cnt);
+        nrays++;
+        if (ANYHIT) {
+            occluded[i] = (unsigned char)(h == 1u);
+        } else {
+            hits[i] = h;
+            rays[i].origin_far.w = r.far_t;
+        }
+    }
+    flush_stats<STATS>(cnt, nrays, stats);
+}
+
+// ------------------------------------------------------------------------
+// extend / connect on the render pipeline's queues
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void extend_kernel(SceneDev sc, QRay *rays, unsigned *hit_ids,
+                                                       const unsigned *n_ptr, unsigned *ovf,
+                                                       StatsDev *stats)
+{
+    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
+    const unsigned n = *n_ptr;
+    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned nthreads = gridDim.x * kBlock;
+    Stack<kBlock, kLdsDepth> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.ovf = ovf + gtid;
+    st.ovf_stride = nthreads;
+    Counters cnt{0, 0, 0};
+    unsigned long long nrays = 0;
+    const float4 *rq = reinterpret_cast<const float4 *>(rays);
+    for (unsigned i = gtid; i < n; i += nthreads) {
+        const float4 a = rq[(size_t)i * 2 + 0];
+        const float4 b = rq[(size_t)i * 2 + 1];
+        RayRegs r;
+        r.o = v3(a.x, a.y, a.z);
+        r.near_t = a.w;
+        r.d = v3(b.x, b.y, b.z);
+        r.far_t = b.w;
+        r.rd = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z); // src/ray.rs:18
+        const unsigned h = trace_ray<false, STATS>(sc, r, st, cnt);
+        nrays++;
+        hit_ids[i] = h;
+        rays[i].far_t = r.far_t;
+    }
+    flush_stats<STATS>(cnt, nrays, stats);
+}
+
+// Any-hit for the shadow queue; an un-occluded ray adds its weight to the
+// radiance slot of its path (src/integrators/integrate_stream.rs:152-161).
+// A path has at most one shadow ray per bounce and launches are stream
+// ordered, so the read-modify-write needs no atomic.
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void connect_kernel(SceneDev sc, const QRay *rays,
+                                                        const ShadowInfo *infos, const unsigned *n_ptr,
+                                                        float *rad_r, float *rad_g, float *rad_b,
+                                                        unsigned *ovf, StatsDev *stats)
+{
+    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
+    const unsigned n = *n_ptr;
+    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned nthreads = gridDim.x * kBlock;
+    Stack<kBlock, kLdsDepth> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.ovf = ovf + gtid;
+    st.ovf_stride = nthreads;
+    Counters cnt{0, 0, 0};
+    unsigned long long nrays = 0;
+    const float4 *rq = reinterpret_cast<const float4 *>(rays);
+    const float4 *iq = reinterpret_cast<const float4 *>(infos);
+    for (unsigned i = gtid; i < n; i += nthreads) {
+        const float4 a = rq[(size_t)i * 2 + 0];
+        const float4 b = rq[(size_t)i * 2 + 1];
+        RayRegs r;
+        r.o = v3(a.x, a.y, a.z);
+        r.near_t = a.w;
+        r.d = v3(b.x, b.y, b.z);
+        r.far_t = b.w;
+        r.rd = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+        const unsigned h = trace_ray<true, STATS>(sc, r, st, cnt);
+        nrays++;
+        if (h != 1u) {
+            const float4 w = iq[i];
+            const unsigned slot = __float_as_uint(w.w);
+            rad_r[slot] += w.x;
+            rad_g[slot] += w.y;
+            rad_b[slot] += w.z;
+        }
+    }
+    flush_stats<STATS>(cnt, nrays, stats);
+}
+
+// ------------------------------------------------------------------------
+// random numbers and sampling
+
+// Counter-based generator keyed by (seed, global pixel, global sample,
+// dimension); u32 -> f32 as rand 0.8.5's Standard: (x >> 8) * 2^-24.
+__device__ __forceinline__ unsigned pcg_hash(unsigned v)
+{
+    unsigned s = v * 747796405u + 2891336453u;
+    unsigned w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+__device__ __forceinline__ unsigned rng_key(unsigned seed_key, unsigned pixel, unsigned sample)
+{
+    return pcg_hash(pcg_hash(seed_key ^ pixel) ^ sample);
+}
+__device__ __forceinline__ float rng_f32(unsigned key, unsigned dim)
+{
+    return (float)(pcg_hash(key ^ dim) >> 8) * (1.f / 16777216.f);
+}
+
+// sin and cos of 2*pi*u, u in [0,1): Cody-Waite reduction by pi/2 and Cephes
+// minimax polynomials, a fixed sequence of un-fused f32 operations (stands in
+// for the libm / `wide` calls of src/brdf.rs:13-16, 82-83, which are not
+// bit-reproducible across targets).
+__device__ __forceinline__ void sincos_2pi(float u, float &s_out, float &c_out)
+{
+    const float b = (2.f * 3.14159274f) * u;
+    const float kf = floorf(b * 0.636619772f + 0.5f);
+    const int k = (int)kf;
+    float r = b - kf * 1.5703125f;
+    r = r - kf * 4.83751297e-4f;
+    r = r - kf * 7.54978995e-8f;
+    const float z = r * r;
+    const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z -
+                     0.5f * z + 1.f;
+    switch (k & 3) {
+    case 0: s_out = sp; c_out = cp; break;
+    case 1: s_out = cp; c_out = -sp; break;
+    case 2: s_out = -sp; c_out = -cp; break;
+    default: s_out = -cp; c_out = sp; break;
+    }
+}
+
+struct Quat {
+    float w;
+    V3 v;
+};
+
+// fast_rotation_between(from, +Z), src/math.rs:48-58; nalgebra's
+// new_normalize divides by sqrt(((i*i+j*j)+k*k)+w*w).  dot == -1 takes the
+// rotation by pi about Y (w = cos(pi/2) in f32).
+__device__ __forceinline__ Quat rotation_to_z(V3 from)
+{
+    const V3 to = v3(0.f, 0.f, 1.f);
+    Quat q;
+    const float dt = dot(from, to);
+    if (dt == -1.f) {
+        q.w = -4.37113883e-8f;
+        q.v = v3(0.f, 1.f, 0.f);
+        return q;
+    }
+    const float w = 1.f + dt;
+    const V3 c = cross(from, to);
+    const float nrm = sqrtf(((c.x * c.x + c.y * c.y) + c.z * c.z) + w * w);
+    q.w = w / nrm;
+    q.v = divs(c, nrm);
+    return q;
+}
+
+// nalgebra UnitQuaternion * Vector3: t = 2*(q.v x x); (t*q.w + q.v x t) + x
+__device__ __forceinline__ V3 rotate(Quat q, V3 x)
+{
+    const V3 t = scale(cross(q.v, x), 2.f);
+    const V3 c = cross(q.v, t);
+    return (scale(t, q.w) + c) + x;
+}
+
+// ------------------------------------------------------------------------
+// generate: camera rays (src/camera.rs:56-135, integrate_stream.rs:14-54)
+
+__device__ __forceinline__ V3 camera_pixel_ray(const CameraDev &cam, unsigned tile_size, unsigned x, unsigned y)
+{
+    // region_top_left of the tile, then the row start, then x advanced by
+    // repeated += (src/camera.rs:72-75, 98-113) so that rounding matches the
+    // reference's per-tile walk.
+    const unsigned rx = x / tile_size * tile_size, ry = y / tile_size * tile_size;
+    const V3 tl = v3(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
+    const V3 sx = v3(cam.step_x[0], cam.step_x[1], cam.step_x[2]);
+    const V3 sy = v3(cam.step_y[0], cam.step_y[1], cam.step_y[2]);
+    const V3 region_tl = (tl + scale(sx, (float)rx)) + scale(sy, (float)ry);
+    const unsigned cy = y - ry, cx = x - rx;
+    V3 cur = region_tl;
+    if (cy > 0) cur = region_tl + scale(sy, (float)cy);
+    for (unsigned i = 0; i < cx; i++) cur = cur + sx;
+    return cur;
+}
+
+__device__ __forceinline__ V3 camera_sample(const CameraDev &cam, V3 pixel_ray, float u0, float u1)
+{
+    const V3 right = v3(cam.right[0], cam.right[1], cam.right[2]);
+    const V3 up = v3(cam.up[0], cam.up[1], cam.up[2]);
+    const V3 off = scale(scale(right, u0 - 0.5f) + scale(up, u1 - 0.5f), cam.pixel_size);
+    return normalize(pixel_ray + off);
+}
+
+// One thread per path slot of the pass.  slot = ((tile_local*ts*ts + py*ts + px)
+// * k + s); tiles are the shard's tiles [tile_begin, tile_begin+tile_count).
+__global__ __launch_bounds__(256) void generate_kernel(CameraDev cam, PassDev ps, QRay *rays, PathInfo *infos,
+                                                      unsigned *n_out, float *rad_r, float *rad_g,
+                                                      float *rad_b)
+{
+    const unsigned slot = blockIdx.x * 256u + threadIdx.x;
+    bool valid = slot < ps.num_slots;
+    unsigned x = 0, y = 0, s = 0;
+    if (valid) {
+        const unsigned k = ps.samples_per_pass;
+        const unsigned ts2 = ps.tile_size * ps.tile_size;
+        s = slot % k;
+        const unsigned p = slot / k;
+        const unsigned pin = p % ts2;
+        const unsigned tl = p / ts2;
+        const unsigned tile = ps.shard_index + (ps.tile_begin + tl) * ps.shard_count;
+        const unsigned tx = tile % ps.tiles_x, ty = tile / ps.tiles_x;
+        x = tx * ps.tile_size + pin % ps.tile_size;
+        y = ty * ps.tile_size + pin / ps.tile_size;
+        rad_r[slot] = 0.f;
+        rad_g[slot] = 0.f;
+        rad_b[slot] = 0.f;
+        valid = (x < ps.width) && (y < ps.height) && (s < ps.samples_this_pass);
+    }
+    const unsigned idx = queue_reserve(valid, n_out);
+    if (!valid) return;
+    const unsigned pixel = y * ps.width + x;
+    const unsigned gs = ps.sample_base + s;
+    const unsigned key = rng_key(ps.seed_key, pixel, gs);
+    const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
+    const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
+    QRay q;
+    q.o[0] = cam.eye[0];
+    q.o[1] = cam.eye[1];
+    q.o[2] = cam.eye[2];
+    q.near_t = 0.f;
+    q.d[0] = d.x;
+    q.d[1] = d.y;
+    q.d[2] = d.z;
+    q.far_t = __builtin_inff();
+    rays[idx] = q;
+    PathInfo pi;
+    pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
+    pi.slot = slot;
+    pi.pixel = pixel;
+    pi.sample = gs;
+    pi.bounces = 0;
+    pi.pad = 0;
+    infos[idx] = pi;
+}
+
+// Primary rays of the whole frame as StreamRays in (pixel, sample) order.
+__global__ __launch_bounds__(256) void generate_stream_kernel(CameraDev cam, PassDev ps, rt_stream_ray_dev *rays,
+                                                             unsigned long long total)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const unsigned s = (unsigned)(i % ps.samples_this_pass);
+    const unsigned pixel = (unsigned)(i / ps.samples_this_pass);
+    const unsigned x = pixel % ps.width, y = pixel / ps.width;
+    const unsigned gs = ps.sample_base + s;
+    const unsigned key = rng_key(ps.seed_key, pixel, gs);
+    const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
+    const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
+    rt_stream_ray_dev r;
+    r.origin_far = make_float4(cam.eye[0], cam.eye[1], cam.eye[2], __builtin_inff());
+    r.dir_recip_near = make_float4(1.f / d.x, 1.f / d.y, 1.f / d.z, 0.f);
+    r.direction = make_float4(d.x, d.y, d.z, 0.f);
+    rays[i] = r;
+}
+
+// ------------------------------------------------------------------------
+// shade: loop body of integrate_tile_stream
+// (src/integrators/integrate_stream.rs:104-138) for every ray of the queue.
+
+__global__ __launch_bounds__(256) void shade_kernel(ShadeArgs a)
+{
+    const unsigned n = *a.n_in;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    bool has_shadow = false, has_bounce = false;
+    QRay sh_ray, bn_ray;
+    ShadowInfo sh_info;
+    PathInfo bn_info;
+    if (i < n) {
+        const unsigned id = a.hit_ids[i];
+        if (id != 0xFFFFFFFFu) {
+            const QRay ray = a.rays_in[i];
+            const PathInfo info = a.infos_in[i];
+            const V3 o = v3(ray.o[0], ray.o[1], ray.o[2]);
+            const V3 d = v3(ray.d[0], ray.d[1], ray.d[2]);
+            const V3 hp = o + scale(d, ray.far_t); // src/ray.rs:40-42
+            const V3 wo = -d;
+            const float4 n4 = reinterpret_cast<const float4 *>(a.normals)[id];
+            const V3 nrm = v3(n4.x, n4.y, n4.z);
+            const V3 pw = v3(info.w[0], info.w[1], info.w[2]);
+
+            // sample_light, src/integrators/common.rs:37-60
+            {
+                const V3 lv = v3(a.light_pos[0], a.light_pos[1], a.light_pos[2]) - hp;
+                float ndotl = dot(nrm, lv);
+                if (!(ndotl * dot(nrm, wo) < 0.f)) {
+                    const float d2 = dot(lv, lv);
+                    const float dist = sqrtf(d2);
+                    const V3 wi = divs(lv, dist);
+                    ndotl = fabsf(ndotl / dist);
+                    const float f = 0.8f / 3.14159274f; // src/brdf.rs:24-26
+                    const V3 li = v3(a.light_intensity[0], a.light_intensity[1], a.light_intensity[2]);
+                    const V3 w = divs(scale(mul(li, v3(f, f, f)), ndotl), d2);
+                    if (!(w.x == 0.f && w.y == 0.f && w.z == 0.f)) {
+                        has_shadow = true;
+                        sh_ray.o[0] = hp.x; sh_ray.o[1] = hp.y; sh_ray.o[2] = hp.z;
+                        sh_ray.near_t = 1e-5f; // SHADOW_RAY_NEAR, common.rs:12
+                        sh_ray.d[0] = wi.x; sh_ray.d[1] = wi.y; sh_ray.d[2] = wi.z;
+                        sh_ray.far_t = dist;
+                        const V3 c = mul(pw, w);
+                        sh_info.w[0] = c.x; sh_info.w[1] = c.y; sh_info.w[2] = c.z;
+                        sh_info.slot = info.slot;
+                    }
+                }
+            }
+
+            // sample_diffuse_ray, src/integrators/common.rs:64-78 + src/brdf.rs:10-17,36-44
+            if (info.bounces < a.max_bounces) {
+                const unsigned key = rng_key(a.seed_key, info.pixel, info.sample);
+                const float u0 = rng_f32(key, 2u + 2u * info.bounces);
+                const float u1 = rng_f32(key, 3u + 2u * info.bounces);
+                const Quat q = rotation_to_z(nrm);
+                const V3 wo_l = rotate(q, wo);
+                const float aa = sqrtf(u0);
+                float sn, cs;
+                sincos_2pi(u1, sn, cs);
+                V3 wi_l = v3(aa * cs, aa * sn, sqrtf(1.f - u0));
+                const float pdf = wi_l.z / 3.14159274f;
+                const float f = 0.8f / 3.14159274f;
+                wi_l.z = copysignf(wi_l.z, wo_l.z);
+                Quat qi = q;
+                qi.v = -q.v;
+                const V3 wi = rotate(qi, wi_l);
+                const float ndotl = fabsf(dot(nrm, wi));
+                const float w = f * ndotl / pdf;
+                has_bounce = true;
+                bn_ray.o[0] = hp.x; bn_ray.o[1] = hp.y; bn_ray.o[2] = hp.z;
+                bn_ray.near_t = 1e-5f;
+                bn_ray.d[0] = wi.x; bn_ray.d[1] = wi.y; bn_ray.d[2] = wi.z;
+                bn_ray.far_t = __builtin_inff();
+                bn_info = info;
+                bn_info.w[0] = pw.x * w; bn_info.w[1] = pw.y * w; bn_info.w[2] = pw.z * w;
+                bn_info.bounces = info.bounces + 1;
+            }
+        }
+    }
+    const unsigned si = queue_reserve(has_shadow, a.n_shadow);
+    if (has_shadow) {
+        a.shadow_rays[si] = sh_ray;
+        a.shadow_infos[si] = sh_info;
+    }
+    const unsigned bi = queue_reserve(has_bounce, a.n_out);
+    if (has_bounce) {
+        a.rays_out[bi] = bn_ray;
+        a.infos_out[bi] = bn_info;
+    }
+}
+
+// ------------------------------------------------------------------------
+// accumulate: per pixel, sum the pass's k sample slots in a fixed order and
+// add (sum, number of samples) to the float4 accumulator (src/main.rs:108,
+// integrate_stream.rs:85-87).
+
+__global__ __launch_bounds__(256) void accumulate_kernel(PassDev ps, const float *rad_r, const float *rad_g,
+                                                        const float *rad_b, float *accum)
+{
+    const unsigned p = blockIdx.x * 256u + threadIdx.x; // pixel slot of the pass
+    const unsigned ts2 = ps.tile_size * ps.tile_size;
+    if (p >= ps.tile_count * ts2) return;
+    const unsigned pin = p % ts2;
+    const unsigned tl = p / ts2;
+    const unsigned tile = ps.shard_index + (ps.tile_begin + tl) * ps.shard_count;
+    const unsigned tx = tile % ps.tiles_x, ty = tile / ps.tiles_x;
+    const unsigned x = tx * ps.tile_size + pin % ps.tile_size;
+    const unsigned y = ty * ps.tile_size + pin / ps.tile_size;
+    if (x >= ps.width || y >= ps.height) return;
+    float r = 0.f, g = 0.f, b = 0.f;
+    const size_t base = (size_t)p * ps.samples_per_pass;
+    for (unsigned s = 0; s < ps.samples_this_pass; s++) {
+        r += rad_r[base + s];
+        g += rad_g[base + s];
+        b += rad_b[base + s];
+    }
+    float4 *dst = reinterpret_cast<float4 *>(accum) + ((size_t)y * ps.width + x);
+    float4 v = *dst;
+    v.x += r;
+    v.y += g;
+    v.z += b;
+    v.w += (float)ps.samples_this_pass;
+    *dst = v;
+}
+
+// color_vec_to_rgb_norm_gamma, src/main.rs:34-41
+__global__ __launch_bounds__(256) void resolve_kernel(const float *accum, unsigned long long npix,
+                                                     unsigned char *rgb)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i >= npix) return;
+    const float4 v = reinterpret_cast<const float4 *>(accum)[i];
+    const float c[3] = {v.x, v.y, v.z};
+    for (int k = 0; k < 3; k++) {
+        const float f = sqrtf(c[k] / v.w) * 255.f;
+        unsigned char b;
+        if (!(f > 0.f)) b = 0;
+        else if (f >= 255.f) b = 255;
+        else b = (unsigned char)f;
+        rgb[i * 3 + k] = b;
+    }
+}
+
+// add n to total_rays when per-visit statistics are off
+__global__ void count_rays_kernel(const unsigned *n_ptr, StatsDev *stats)
+{
+    atomicAdd(&stats->total_rays, (unsigned long long)*n_ptr);
+}
+
+// ------------------------------------------------------------------------
+// launchers
+
+static unsigned trace_grid(unsigned n, unsigned max_blocks)
+{
+    unsigned need = (n + kBlock - 1) / kBlock;
+    if (need < 1) need = 1;
+    return need < max_blocks ? need : max_blocks;
+}
+
+void launch_trace_stream(bool anyhit, bool stats, const SceneDev &sc, rt_stream_ray_dev *rays, unsigned *hits,
+                         unsigned char *occluded, unsigned n, unsigned *ovf, StatsDev *dstats,
+                         unsigned max_blocks, hipStream_t stream)
+{
+    if (n == 0) return;
+    const unsigned grid = trace_grid(n, max_blocks);
+    if (anyhit) {
+        if (stats)
+            hipLaunchKernelGGL((trace_stream_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
+                               hits, occluded, n, ovf, dstats);
+        else
+            hipLaunchKernelGGL((trace_stream_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
+                               hits, occluded, n, ovf, dstats);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL((trace_stream_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
+                               hits, occluded, n, ovf, dstats);
+        else
+            hipLaunchKernelGGL((trace_stream_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
+                               hits, occluded, n, ovf, dstats);
+    }
+}
+
+void launch_extend(bool stats, const SceneDev &sc, QRay *rays, unsigned *hit_ids, const unsigned *n_ptr,
+                   unsigned n_upper, unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream)
+{
+    const unsigned grid = trace_grid(n_upper, max_blocks);
+    if (stats)
+        hipLaunchKernelGGL((extend_kernel<true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, hit_ids, n_ptr,
+                           ovf, dstats);
+    else
+        hipLaunchKernelGGL((extend_kernel<false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, hit_ids, n_ptr,
+                           ovf, dstats);
+}
+
+void launch_connect(bool stats, const SceneDev &sc, const QRay *rays, const ShadowInfo *infos,
+                    const unsigned *n_ptr, unsigned n_upper, float *rad_r, float *rad_g, float *rad_b,
+                    unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream)
+{
+    const unsigned grid = trace_grid(n_upper, max_blocks);
+    if (stats)
+        hipLaunchKernelGGL((connect_kernel<true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, infos, n_ptr,
+                           rad_r, rad_g, rad_b, ovf, dstats);
+    else
+        hipLaunchKernelGGL((connect_kernel<false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, infos, n_ptr,
+                           rad_r, rad_g, rad_b, ovf, dstats);
+}
+
+void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream)
+{
+    hipLaunchKernelGGL(count_rays_kernel, dim3(1), dim3(1), 0, stream, n_ptr, dstats);
+}
+
+void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,
+                     float *rad_r, float *rad_g, float *rad_b, hipStream_t stream)
+{
+    const unsigned grid = (ps.num_slots + 255u) / 256u;
+    if (grid == 0) return;
+    hipLaunchKernelGGL(generate_kernel, dim3(grid), dim3(256), 0, stream, cam, ps, rays, infos, n_out, rad_r,
+                       rad_g, rad_b);
+}
+
+void launch_generate_stream(const CameraDev &cam, const PassDev &ps, rt_stream_ray_dev *rays,
+                            unsigned long long total, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((total + 255ull) / 256ull);
+    if (grid == 0) return;
+    hipLaunchKernelGGL(generate_stream_kernel, dim3(grid), dim3(256), 0, stream, cam, ps, rays, total);
+}
+
+void launch_shade(const ShadeArgs &a, unsigned n_upper, hipStream_t stream)
+{
+    const unsigned grid = (n_upper + 255u) / 256u;
+    if (grid == 0) return;
+    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(256), 0, stream, a);
+}
+
+void launch_accumulate(const PassDev &ps, const float *rad_r, const float *rad_g, const float *rad_b,
+                       float *accum, hipStream_t stream)
+{
+    const unsigned npx = ps.tile_count * ps.tile_size * ps.tile_size;
+    const unsigned grid = (npx + 255u) / 256u;
+    if (grid == 0) return;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, stream, ps, rad_r, rad_g, rad_b, accum);
+}
+
+void launch_resolve(const float *accum, unsigned long long npix, unsigned char *rgb, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((npix + 255ull) / 256ull);
+    if (grid == 0) return;
+    hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, stream, accum, npix, rgb);
+}
+
+int trace_blocks_per_cu()
+{
+    int a = 0, b = 0, c = 0, d = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, trace_stream_kernel<false, false>, kBlock, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, trace_stream_kernel<false, true>, kBlock, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, extend_kernel<false>, kBlock, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, connect_kernel<false>, kBlock, 0);
+    int m = a;
+    if (b > m) m = b;
+    if (c > m) m = c;
+    if (d > m) m = d;
+    if (m < 1) m = 1;
+    if (m > 8) m = 8;
+    return m;
+}
+
+} // namespace rtc

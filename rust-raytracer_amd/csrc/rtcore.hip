@@ -1,0 +1,861 @@
+// C ABI of the MI355X ray-tracing core (see include/rtcore.h).
+//
+// Host side only: argument checks, scene upload, workspace, pass planning and
+// kernel sequencing.  All device work is in kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rtcore.h"
+#include "bvh_build.hpp"
+#include "device_layout.h"
+#include "kernels.h"
+
+using namespace rtc;
+
+// ------------------------------------------------------------------------
+// errors
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+extern "C" const char *rt_last_error(void) { return g_err.c_str(); }
+extern "C" const char *rt_version(void) { return "rtcore-gfx950 0.1"; }
+
+// ------------------------------------------------------------------------
+// context
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return RT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return fail(RT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        bytes = need;
+        return RT_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+    int kind; // 0 extend, 1 connect, 2 other
+};
+
+struct Workspace {
+    DevBuf rays[2], infos[2], hit_ids, shadow_rays, shadow_infos, rad, counters;
+    uint64_t paths = 0;
+};
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int num_cus = 0;
+    unsigned max_blocks = 0; // resident trace blocks
+    hipStream_t stream = nullptr;
+    DevBuf ovf;             // traversal stack overflow area
+    unsigned ovf_depth = 0; // entries per thread available in ovf
+    DevBuf dstats;
+    Workspace ws;
+    uint64_t max_paths = 1ull << 24;
+    DevBuf io_a, io_b; // staging for the host-buffer entry points
+    std::vector<TimedLaunch> pool;
+    size_t used = 0;
+    bool timing = true;
+};
+
+struct rt_scene {
+    rt_ctx *ctx = nullptr;
+    HostBvh host;
+    uint32_t num_triangles = 0;
+    DevBuf nodes, tris, big, normals;
+    SceneDev dev{};
+    uint64_t device_bytes = 0;
+};
+
+static int ctx_set_device(rt_ctx *ctx) { HIP_TRY(hipSetDevice(ctx->device)); return RT_OK; }
+
+static int ensure_overflow(rt_ctx *ctx, unsigned max_depth)
+{
+    unsigned need = max_depth + 1 > (unsigned)RTC_LDS_STACK_DEPTH ? max_depth + 1 - RTC_LDS_STACK_DEPTH : 1;
+    if (need <= ctx->ovf_depth) return RT_OK;
+    size_t threads = (size_t)ctx->max_blocks * RTC_TRACE_BLOCK;
+    int rc = ctx->ovf.ensure(threads * need * sizeof(unsigned));
+    if (rc != RT_OK) return rc;
+    ctx->ovf_depth = need;
+    return RT_OK;
+}
+
+static int timed_begin(rt_ctx *ctx, int kind, hipStream_t s, size_t *slot)
+{
+    *slot = (size_t)-1;
+    if (!ctx->timing) return RT_OK;
+    if (ctx->used == ctx->pool.size()) {
+        TimedLaunch t{};
+        HIP_TRY(hipEventCreate(&t.start));
+        HIP_TRY(hipEventCreate(&t.stop));
+        ctx->pool.push_back(t);
+    }
+    *slot = ctx->used++;
+    ctx->pool[*slot].kind = kind;
+    HIP_TRY(hipEventRecord(ctx->pool[*slot].start, s));
+    return RT_OK;
+}
+
+static int timed_end(rt_ctx *ctx, size_t slot, hipStream_t s)
+{
+    if (slot == (size_t)-1) return RT_OK;
+    HIP_TRY(hipEventRecord(ctx->pool[slot].stop, s));
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
+{
+    if (!out) return fail(RT_ERR_INVALID, "rt_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(RT_ERR_INVALID, "rt_ctx_create: device %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(RT_ERR_NOMEM, "rt_ctx_create: out of host memory");
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(RT_ERR_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    int per_cu = trace_blocks_per_cu();
+    if (const char *env = getenv("RTCORE_BLOCKS_PER_CU")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 16) per_cu = v;
+    }
+    ctx->max_blocks = (unsigned)(ctx->num_cus * per_cu);
+    if (const char *env = getenv("RTCORE_NO_TIMING")) ctx->timing = !(env[0] == '1');
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(RT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    int rc = ctx->dstats.ensure(sizeof(StatsDev));
+    if (rc == RT_OK) rc = ensure_overflow(ctx, 0);
+    if (rc != RT_OK) {
+        rt_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+extern "C" void rt_ctx_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &t : ctx->pool) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    ctx->ovf.release();
+    ctx->dstats.release();
+    ctx->io_a.release();
+    ctx->io_b.release();
+    Workspace &w = ctx->ws;
+    w.rays[0].release(); w.rays[1].release(); w.infos[0].release(); w.infos[1].release();
+    w.hit_ids.release(); w.shadow_rays.release(); w.shadow_infos.release(); w.rad.release();
+    w.counters.release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int rt_ctx_set_max_paths(rt_ctx *ctx, uint64_t max_paths)
+{
+    if (!ctx) return fail(RT_ERR_INVALID, "rt_ctx_set_max_paths: ctx is NULL");
+    if (max_paths < 4096 || max_paths > (1ull << 30))
+        return fail(RT_ERR_LIMIT, "rt_ctx_set_max_paths: %llu outside [4096, 2^30]", (unsigned long long)max_paths);
+    ctx->max_paths = max_paths;
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches[3])
+{
+    if (!ctx || !ms || !launches) return fail(RT_ERR_INVALID, "rt_ctx_last_kernel_ms: NULL argument");
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    for (int k = 0; k < 3; k++) {
+        ms[k] = 0.f;
+        launches[k] = 0;
+    }
+    for (size_t i = 0; i < ctx->used; i++) {
+        TimedLaunch &t = ctx->pool[i];
+        HIP_TRY(hipEventSynchronize(t.stop));
+        float v = 0.f;
+        HIP_TRY(hipEventElapsedTime(&v, t.start, t.stop));
+        ms[t.kind] += v;
+        launches[t.kind] += 1;
+    }
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------
+// scene
+
+extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num_vertices,
+                               const uint32_t *indices, uint32_t num_triangles, const float *geom_normals,
+                               rt_scene **out)
+{
+    if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is NULL");
+    *out = nullptr;
+    if (!ctx || !positions || !indices || !geom_normals)
+        return fail(RT_ERR_INVALID, "rt_scene_create: NULL argument");
+    if (num_triangles == 0 || num_vertices == 0)
+        return fail(RT_ERR_INVALID, "rt_scene_create: empty mesh");
+    if (num_triangles >= kMaxPackedFirst)
+        return fail(RT_ERR_LIMIT, "rt_scene_create: %u triangles, limit is %u", num_triangles, kMaxPackedFirst - 1);
+    for (size_t i = 0; i < (size_t)num_triangles * 3; i++)
+        if (indices[i] >= num_vertices)
+            return fail(RT_ERR_INVALID, "rt_scene_create: index %u at %zu out of range (%u vertices)", indices[i],
+                        i, num_vertices);
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+
+    rt_scene *sc = new (std::nothrow) rt_scene();
+    if (!sc) return fail(RT_ERR_NOMEM, "rt_scene_create: out of host memory");
+    sc->ctx = ctx;
+    sc->num_triangles = num_triangles;
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned threads = hw ? std::min(hw, 16u) : 4u;
+    if (const char *env = getenv("RTCORE_BUILD_THREADS")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 256) threads = (unsigned)v;
+    }
+    try {
+        build_bvh(positions, num_vertices, indices, num_triangles, threads, sc->host);
+    } catch (const std::exception &ex) {
+        delete sc;
+        return fail(RT_ERR_NOMEM, "rt_scene_create: BVH build failed: %s", ex.what());
+    }
+    const HostBvh &hb = sc->host;
+    if (hb.stats.max_depth > 1024) {
+        delete sc;
+        return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth %u beyond the supported 1024", hb.stats.max_depth);
+    }
+
+    // device images
+    std::vector<BigLeaf> big;
+    auto pack_ref = [&](uint32_t ref, uint32_t count) -> uint32_t {
+        if (!(ref & kLeafBit)) return ref;
+        uint32_t first = ref & 0x7FFFFFFFu;
+        if (count >= 1 && count <= 8) return kLeafBit | (first << 3) | (count - 1);
+        big.push_back(BigLeaf{first, count});
+        return kLeafBit | kBigLeafBit | (uint32_t)(big.size() - 1);
+    };
+    std::vector<DevNode> dn(hb.nodes.size());
+    for (size_t i = 0; i < hb.nodes.size(); i++) {
+        const rt_flat_node &s = hb.nodes[i];
+        DevNode &d = dn[i];
+        memcpy(d.bx, s.bx, sizeof d.bx);
+        memcpy(d.by, s.by, sizeof d.by);
+        memcpy(d.bz, s.bz, sizeof d.bz);
+        d.left = pack_ref(s.left, s.left_count);
+        d.right = pack_ref(s.right, s.right_count);
+        d.pad0 = d.pad1 = 0;
+    }
+    uint32_t root = pack_ref(hb.root_ref, hb.root_count);
+    std::vector<DevTri> dt(num_triangles);
+    for (uint32_t slot = 0; slot < num_triangles; slot++) {
+        uint32_t t = hb.order[slot];
+        const float *a = positions + 3 * (size_t)indices[3 * (size_t)t + 0];
+        const float *b = positions + 3 * (size_t)indices[3 * (size_t)t + 1];
+        const float *c = positions + 3 * (size_t)indices[3 * (size_t)t + 2];
+        DevTri &d = dt[slot];
+        for (int k = 0; k < 3; k++) { // src/triangle_opt.rs:72-81
+            d.v0[k] = a[k];
+            d.e1[k] = b[k] - a[k];
+            d.e2[k] = c[k] - a[k];
+        }
+        d.id = t;
+        d.pad[0] = d.pad[1] = 0;
+    }
+    std::vector<float> n4((size_t)num_triangles * 4);
+    for (uint32_t t = 0; t < num_triangles; t++) {
+        n4[4 * (size_t)t + 0] = geom_normals[3 * (size_t)t + 0];
+        n4[4 * (size_t)t + 1] = geom_normals[3 * (size_t)t + 1];
+        n4[4 * (size_t)t + 2] = geom_normals[3 * (size_t)t + 2];
+        n4[4 * (size_t)t + 3] = 0.f;
+    }
+
+    auto upload = [&](DevBuf &buf, const void *src, size_t bytes) -> int {
+        int r = buf.ensure(bytes ? bytes : 16);
+        if (r != RT_OK) return r;
+        if (bytes) HIP_TRY(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+        sc->device_bytes += bytes;
+        return RT_OK;
+    };
+    rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
+    if (rc == RT_OK) rc = upload(sc->tris, dt.data(), dt.size() * sizeof(DevTri));
+    if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
+    if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
+    if (rc == RT_OK) rc = ensure_overflow(ctx, hb.stats.max_depth);
+    if (rc != RT_OK) {
+        rt_scene_destroy(sc);
+        return rc;
+    }
+    sc->dev.nodes = (const DevNode *)sc->nodes.p;
+    sc->dev.tris = (const DevTri *)sc->tris.p;
+    sc->dev.big_leaves = (const BigLeaf *)sc->big.p;
+    sc->dev.normals = (const float *)sc->normals.p;
+    sc->dev.root_ref = root;
+    sc->dev.max_depth = hb.stats.max_depth;
+    *out = sc;
+    return RT_OK;
+}
+
+extern "C" int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                                 uint32_t num_triangles, uint32_t threads, rt_flat_node *nodes, uint32_t *order,
+                                 rt_scene_info *info, rt_bvh_stats *stats)
+{
+    if (!positions || !indices || !nodes || !order)
+        return fail(RT_ERR_INVALID, "rt_bvh_build_host: NULL argument");
+    if (num_triangles == 0 || num_vertices == 0) return fail(RT_ERR_INVALID, "rt_bvh_build_host: empty mesh");
+    for (size_t i = 0; i < (size_t)num_triangles * 3; i++)
+        if (indices[i] >= num_vertices)
+            return fail(RT_ERR_INVALID, "rt_bvh_build_host: index %u at %zu out of range", indices[i], i);
+    if (threads == 0) {
+        unsigned hw = std::thread::hardware_concurrency();
+        threads = hw ? std::min(hw, 16u) : 4u;
+    }
+    HostBvh hb;
+    try {
+        build_bvh(positions, num_vertices, indices, num_triangles, threads, hb);
+    } catch (const std::exception &ex) {
+        return fail(RT_ERR_NOMEM, "rt_bvh_build_host: %s", ex.what());
+    }
+    if (!hb.nodes.empty()) memcpy(nodes, hb.nodes.data(), hb.nodes.size() * sizeof(rt_flat_node));
+    memcpy(order, hb.order.data(), hb.order.size() * sizeof(uint32_t));
+    if (info) {
+        info->num_triangles = num_triangles;
+        info->num_inner_nodes = (uint32_t)hb.nodes.size();
+        info->root_ref = hb.root_ref;
+        info->root_count = hb.root_count;
+        info->device_bytes = 0;
+    }
+    if (stats) *stats = hb.stats;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene *sc)
+{
+    if (!sc) return;
+    (void)hipSetDevice(sc->ctx->device);
+    (void)hipDeviceSynchronize();
+    sc->nodes.release();
+    sc->tris.release();
+    sc->big.release();
+    sc->normals.release();
+    delete sc;
+}
+
+extern "C" int rt_scene_stats(const rt_scene *sc, rt_bvh_stats *out)
+{
+    if (!sc || !out) return fail(RT_ERR_INVALID, "rt_scene_stats: NULL argument");
+    *out = sc->host.stats;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_get_info(const rt_scene *sc, rt_scene_info *out)
+{
+    if (!sc || !out) return fail(RT_ERR_INVALID, "rt_scene_get_info: NULL argument");
+    out->num_triangles = sc->num_triangles;
+    out->num_inner_nodes = (uint32_t)sc->host.nodes.size();
+    out->root_ref = sc->host.root_ref;
+    out->root_count = sc->host.root_count;
+    out->device_bytes = sc->device_bytes;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_get_flat(const rt_scene *sc, rt_flat_node *nodes, rt_flat_tri *tris)
+{
+    if (!sc) return fail(RT_ERR_INVALID, "rt_scene_get_flat: scene is NULL");
+    if (nodes && !sc->host.nodes.empty())
+        memcpy(nodes, sc->host.nodes.data(), sc->host.nodes.size() * sizeof(rt_flat_node));
+    if (tris) {
+        int rc = ctx_set_device(sc->ctx);
+        if (rc != RT_OK) return rc;
+        std::vector<DevTri> dt(sc->num_triangles);
+        HIP_TRY(hipMemcpy(dt.data(), sc->tris.p, dt.size() * sizeof(DevTri), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < sc->num_triangles; i++) {
+            memcpy(tris[i].v0, dt[i].v0, sizeof dt[i].v0);
+            memcpy(tris[i].v0v1, dt[i].e1, sizeof dt[i].e1);
+            memcpy(tris[i].v0v2, dt[i].e2, sizeof dt[i].e2);
+            tris[i].id = dt[i].id;
+            tris[i].pad[0] = tris[i].pad[1] = 0;
+        }
+    }
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------
+// trace on StreamRay arrays
+
+static void stats_from_dev(const StatsDev &d, rt_trace_stats *s)
+{
+    s->total_rays += d.total_rays;
+    s->inner_visit += d.inner_rays;
+    s->inner_rays += d.inner_rays;
+    s->leaf_visit += d.leaf_rays;
+    s->leaf_rays += d.leaf_rays;
+    s->leaf_objs += d.obj_intersect;
+    s->obj_intersect += d.obj_intersect;
+}
+
+static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_rays, uint32_t *d_hits,
+                               uint8_t *d_occ, uint32_t n, rt_trace_stats *stats, hipStream_t s, bool sync_stats)
+{
+    rt_ctx *ctx = sc->ctx;
+    ctx->used = 0;
+    bool want = stats != nullptr;
+    if (want) HIP_TRY(hipMemsetAsync(ctx->dstats.p, 0, sizeof(StatsDev), s));
+    size_t slot;
+    int rc = timed_begin(ctx, anyhit ? 1 : 0, s, &slot);
+    if (rc != RT_OK) return rc;
+    launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, (unsigned *)ctx->ovf.p,
+                        (StatsDev *)ctx->dstats.p, ctx->max_blocks, s);
+    HIP_TRY(hipGetLastError());
+    rc = timed_end(ctx, slot, s);
+    if (rc != RT_OK) return rc;
+    if (want && sync_stats) {
+        StatsDev h{};
+        HIP_TRY(hipMemcpyAsync(&h, ctx->dstats.p, sizeof h, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        stats_from_dev(h, stats);
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_intersect_stream_device(rt_scene *sc, rt_stream_ray *d_rays, uint32_t *d_hits, uint32_t n,
+                                          rt_trace_stats *stats, void *hip_stream)
+{
+    if (!sc) return fail(RT_ERR_INVALID, "rt_intersect_stream_device: scene is NULL");
+    if (n && (!d_rays || !d_hits)) return fail(RT_ERR_INVALID, "rt_intersect_stream_device: NULL buffer");
+    int rc = ctx_set_device(sc->ctx);
+    if (rc != RT_OK) return rc;
+    return trace_stream_device(sc, false, (rt_stream_ray_dev *)d_rays, d_hits, nullptr, n, stats,
+                               (hipStream_t)hip_stream, true);
+}
+
+extern "C" int rt_occluded_stream_device(rt_scene *sc, const rt_stream_ray *d_rays, uint8_t *d_occluded,
+                                         uint32_t n, rt_trace_stats *stats, void *hip_stream)
+{
+    if (!sc) return fail(RT_ERR_INVALID, "rt_occluded_stream_device: scene is NULL");
+    if (n && (!d_rays || !d_occluded)) return fail(RT_ERR_INVALID, "rt_occluded_stream_device: NULL buffer");
+    int rc = ctx_set_device(sc->ctx);
+    if (rc != RT_OK) return rc;
+    return trace_stream_device(sc, true, (rt_stream_ray_dev *)d_rays, nullptr, d_occluded, n, stats,
+                               (hipStream_t)hip_stream, true);
+}
+
+extern "C" int rt_intersect_stream(rt_scene *sc, rt_stream_ray *rays, uint32_t *hits, uint32_t n,
+                                   rt_trace_stats *stats)
+{
+    if (!sc) return fail(RT_ERR_INVALID, "rt_intersect_stream: scene is NULL");
+    if (n && (!rays || !hits)) return fail(RT_ERR_INVALID, "rt_intersect_stream: NULL buffer");
+    if (n == 0) return RT_OK;
+    rt_ctx *ctx = sc->ctx;
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    rc = ctx->io_a.ensure((size_t)n * sizeof(rt_stream_ray));
+    if (rc == RT_OK) rc = ctx->io_b.ensure((size_t)n * sizeof(uint32_t));
+    if (rc != RT_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, rays, (size_t)n * sizeof(rt_stream_ray), hipMemcpyHostToDevice, s));
+    rc = trace_stream_device(sc, false, (rt_stream_ray_dev *)ctx->io_a.p, (uint32_t *)ctx->io_b.p, nullptr, n,
+                             stats, s, true);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rays, ctx->io_a.p, (size_t)n * sizeof(rt_stream_ray), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hits, ctx->io_b.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+extern "C" int rt_occluded_stream(rt_scene *sc, const rt_stream_ray *rays, uint8_t *occluded, uint32_t n,
+                                  rt_trace_stats *stats)
+{
+    if (!sc) return fail(RT_ERR_INVALID, "rt_occluded_stream: scene is NULL");
+    if (n && (!rays || !occluded)) return fail(RT_ERR_INVALID, "rt_occluded_stream: NULL buffer");
+    if (n == 0) return RT_OK;
+    rt_ctx *ctx = sc->ctx;
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    rc = ctx->io_a.ensure((size_t)n * sizeof(rt_stream_ray));
+    if (rc == RT_OK) rc = ctx->io_b.ensure((size_t)n);
+    if (rc != RT_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, rays, (size_t)n * sizeof(rt_stream_ray), hipMemcpyHostToDevice, s));
+    rc = trace_stream_device(sc, true, (rt_stream_ray_dev *)ctx->io_a.p, nullptr, (uint8_t *)ctx->io_b.p, n,
+                             stats, s, true);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(occluded, ctx->io_b.p, (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------
+// camera frame, src/camera.rs:25-37 and 56-88, on the host in f32
+
+namespace {
+
+struct H3 {
+    float x, y, z;
+};
+inline H3 h3(const float *p) { return H3{p[0], p[1], p[2]}; }
+inline H3 hadd(H3 a, H3 b) { return H3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline H3 hsub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 hscale(H3 a, float s) { return H3{a.x * s, a.y * s, a.z * s}; }
+inline float hdot(H3 a, H3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline H3 hnorm(H3 a)
+{
+    float n = sqrtf(hdot(a, a));
+    return H3{a.x / n, a.y / n, a.z / n};
+}
+inline void put(float *d, H3 v)
+{
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+}
+
+CameraDev make_camera(const rt_camera &c, uint32_t w, uint32_t h)
+{
+    CameraDev o{};
+    H3 eye = h3(c.eye);
+    H3 fwd = hnorm(hsub(h3(c.target), eye));
+    H3 right = hnorm(hcross(fwd, h3(c.up)));
+    H3 up = hcross(right, fwd);
+    const float pi = 3.14159274f;
+    float half_w = tanf(c.fov_deg * (pi / 180.f) / 2.f);
+    float half_h = half_w * (((float)h - 1.f) / ((float)w - 1.f));
+    H3 step_x = hscale(right, 2.f * half_w / ((float)w - 1.f));
+    H3 step_y = hscale(H3{-up.x, -up.y, -up.z}, 2.f * half_h / ((float)h - 1.f));
+    H3 tl = hadd(hsub(fwd, hscale(right, half_w)), hscale(up, half_h));
+    put(o.eye, eye);
+    put(o.right, right);
+    put(o.up, up);
+    put(o.top_left, tl);
+    put(o.step_x, step_x);
+    put(o.step_y, step_y);
+    o.pixel_size = half_w * 2.f / ((float)w - 1.f);
+    return o;
+}
+
+inline uint32_t pcg_hash_host(uint32_t v)
+{
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+inline uint32_t seed_key_of(uint64_t seed)
+{
+    uint32_t h = pcg_hash_host((uint32_t)seed ^ 0x9E3779B9u);
+    return pcg_hash_host(h ^ (uint32_t)(seed >> 32));
+}
+
+int check_params(const rt_render_params *p, const char *who)
+{
+    if (p->width < 2 || p->height < 2 || p->width > 65536 || p->height > 65536)
+        return fail(RT_ERR_INVALID, "%s: image size %ux%u outside [2, 65536]", who, p->width, p->height);
+    if (p->tile_size < 1 || p->tile_size > 256)
+        return fail(RT_ERR_INVALID, "%s: tile_size %u outside [1, 256]", who, p->tile_size);
+    if (p->max_bounces > 255) return fail(RT_ERR_INVALID, "%s: max_bounces %u > 255", who, p->max_bounces);
+    uint32_t sc = p->shard_count ? p->shard_count : 1;
+    if (p->shard_index >= sc)
+        return fail(RT_ERR_INVALID, "%s: shard_index %u >= shard_count %u", who, p->shard_index, sc);
+    if ((uint64_t)p->sample_offset + p->samples > 0xFFFFFFFFull)
+        return fail(RT_ERR_INVALID, "%s: sample range overflows u32", who);
+    return RT_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------
+// render
+
+static int ensure_workspace(rt_ctx *ctx, uint64_t paths, uint32_t ncounters)
+{
+    Workspace &w = ctx->ws;
+    int rc = RT_OK;
+    for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.rays[i].ensure(paths * sizeof(QRay));
+    for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.infos[i].ensure(paths * sizeof(PathInfo));
+    if (rc == RT_OK) rc = w.hit_ids.ensure(paths * sizeof(uint32_t));
+    if (rc == RT_OK) rc = w.shadow_rays.ensure(paths * sizeof(QRay));
+    if (rc == RT_OK) rc = w.shadow_infos.ensure(paths * sizeof(ShadowInfo));
+    if (rc == RT_OK) rc = w.rad.ensure(paths * 3 * sizeof(float));
+    if (rc == RT_OK) rc = w.counters.ensure((size_t)ncounters * sizeof(uint32_t));
+    if (rc == RT_OK) w.paths = std::max(w.paths, paths);
+    return rc;
+}
+
+extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_light *light,
+                                const rt_render_params *params, float *d_accum, rt_trace_stats *stats,
+                                void *hip_stream)
+{
+    if (!sc || !camera || !light || !params || !d_accum)
+        return fail(RT_ERR_INVALID, "rt_render_device: NULL argument");
+    int rc = check_params(params, "rt_render_device");
+    if (rc != RT_OK) return rc;
+    rt_ctx *ctx = sc->ctx;
+    rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    ctx->used = 0;
+    if (params->samples == 0) return RT_OK;
+
+    const uint32_t ts = params->tile_size, ts2 = ts * ts;
+    const uint32_t tiles_x = (params->width + ts - 1) / ts, tiles_y = (params->height + ts - 1) / ts;
+    const uint64_t ntiles = (uint64_t)tiles_x * tiles_y;
+    const uint32_t shard_count = params->shard_count ? params->shard_count : 1;
+    const uint32_t my_tiles =
+        (uint32_t)((ntiles + shard_count - 1 - params->shard_index) / shard_count); // i % sc == si
+    if (my_tiles == 0) return RT_OK;
+
+    // pass plan: tiles_per_pass tiles x k samples <= max_paths slots
+    uint64_t cap = ctx->max_paths;
+    if (cap < ts2) return fail(RT_ERR_LIMIT, "rt_render_device: max_paths %llu below one tile (%u)",
+                               (unsigned long long)cap, ts2);
+    uint32_t k = params->samples_per_pass ? params->samples_per_pass : 0;
+    uint32_t tiles_per_pass;
+    if ((uint64_t)my_tiles * ts2 <= cap) {
+        tiles_per_pass = my_tiles;
+        uint64_t kmax = cap / ((uint64_t)my_tiles * ts2);
+        if (k == 0 || k > kmax) k = (uint32_t)std::min<uint64_t>(kmax, 0xFFFFFFFFu);
+    } else {
+        k = 1;
+        tiles_per_pass = (uint32_t)(cap / ts2);
+    }
+    k = std::min(k, params->samples);
+    if (k < 1) k = 1;
+    const uint64_t slots = (uint64_t)tiles_per_pass * ts2 * k;
+    if (slots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rt_render_device: pass of %llu paths exceeds 2^32",
+                                           (unsigned long long)slots);
+
+    const uint32_t nb = params->max_bounces + 1;  // extend launches per pass
+    const uint32_t ncounters = 2 * nb + 2;        // ray count per depth (+1), shadow count per depth
+    rc = ensure_workspace(ctx, slots, ncounters);
+    if (rc != RT_OK) return rc;
+    Workspace &w = ctx->ws;
+
+    const CameraDev cam = make_camera(*camera, params->width, params->height);
+    const uint32_t seed_key = seed_key_of(params->seed);
+    const bool want = stats != nullptr;
+    const bool visit = want && (params->flags & RT_RENDER_VISIT_STATS);
+    StatsDev *dstats = (StatsDev *)ctx->dstats.p;
+    if (want) HIP_TRY(hipMemsetAsync(dstats, 0, sizeof(StatsDev), s));
+
+    float *rad_r = (float *)w.rad.p, *rad_g = rad_r + slots, *rad_b = rad_g + slots;
+    uint32_t *counters = (uint32_t *)w.counters.p;
+    unsigned *ovf = (unsigned *)ctx->ovf.p;
+
+    for (uint32_t tile0 = 0; tile0 < my_tiles; tile0 += tiles_per_pass) {
+        const uint32_t tcount = std::min(tiles_per_pass, my_tiles - tile0);
+        for (uint32_t s0 = 0; s0 < params->samples; s0 += k) {
+            PassDev ps{};
+            ps.width = params->width;
+            ps.height = params->height;
+            ps.tile_size = ts;
+            ps.tiles_x = tiles_x;
+            ps.shard_index = params->shard_index;
+            ps.shard_count = shard_count;
+            ps.tile_begin = tile0;
+            ps.tile_count = tcount;
+            ps.samples_per_pass = k;
+            ps.samples_this_pass = std::min(k, params->samples - s0);
+            ps.sample_base = params->sample_offset + s0;
+            ps.num_slots = tcount * ts2 * k;
+            ps.seed_key = seed_key;
+
+            HIP_TRY(hipMemsetAsync(counters, 0, (size_t)ncounters * sizeof(uint32_t), s));
+            uint32_t *n_ray = counters;          // [0..nb]
+            uint32_t *n_sh = counters + nb + 1;  // [0..nb-1]
+            int cur = 0;
+            size_t slot;
+            rc = timed_begin(ctx, 2, s, &slot);
+            if (rc != RT_OK) return rc;
+            launch_generate(cam, ps, (QRay *)w.rays[cur].p, (PathInfo *)w.infos[cur].p, &n_ray[0], rad_r, rad_g,
+                            rad_b, s);
+            rc = timed_end(ctx, slot, s);
+            if (rc != RT_OK) return rc;
+            for (uint32_t b = 0; b < nb; b++) {
+                rc = timed_begin(ctx, 0, s, &slot);
+                if (rc != RT_OK) return rc;
+                launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
+                              ps.num_slots, ovf, dstats, ctx->max_blocks, s);
+                rc = timed_end(ctx, slot, s);
+                if (rc != RT_OK) return rc;
+                if (want && !visit) launch_count_rays(&n_ray[b], dstats, s);
+
+                ShadeArgs a{};
+                a.rays_in = (const QRay *)w.rays[cur].p;
+                a.infos_in = (const PathInfo *)w.infos[cur].p;
+                a.hit_ids = (const uint32_t *)w.hit_ids.p;
+                a.n_in = &n_ray[b];
+                a.normals = sc->dev.normals;
+                a.rays_out = (QRay *)w.rays[cur ^ 1].p;
+                a.infos_out = (PathInfo *)w.infos[cur ^ 1].p;
+                a.n_out = &n_ray[b + 1];
+                a.shadow_rays = (QRay *)w.shadow_rays.p;
+                a.shadow_infos = (ShadowInfo *)w.shadow_infos.p;
+                a.n_shadow = &n_sh[b];
+                memcpy(a.light_pos, light->pos, sizeof a.light_pos);
+                memcpy(a.light_intensity, light->intensity, sizeof a.light_intensity);
+                a.max_bounces = params->max_bounces;
+                a.seed_key = seed_key;
+                rc = timed_begin(ctx, 2, s, &slot);
+                if (rc != RT_OK) return rc;
+                launch_shade(a, ps.num_slots, s);
+                rc = timed_end(ctx, slot, s);
+                if (rc != RT_OK) return rc;
+
+                rc = timed_begin(ctx, 1, s, &slot);
+                if (rc != RT_OK) return rc;
+                launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
+                               &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, ovf, dstats, ctx->max_blocks, s);
+                rc = timed_end(ctx, slot, s);
+                if (rc != RT_OK) return rc;
+                if (want && !visit) launch_count_rays(&n_sh[b], dstats, s);
+                cur ^= 1;
+            }
+            rc = timed_begin(ctx, 2, s, &slot);
+            if (rc != RT_OK) return rc;
+            launch_accumulate(ps, rad_r, rad_g, rad_b, d_accum, s);
+            rc = timed_end(ctx, slot, s);
+            if (rc != RT_OK) return rc;
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (want) {
+        StatsDev h{};
+        HIP_TRY(hipMemcpyAsync(&h, dstats, sizeof h, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (visit) {
+            stats_from_dev(h, stats);
+        } else {
+            stats->total_rays += h.total_rays;
+        }
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_scene *sc, const rt_camera *camera, const rt_light *light,
+                         const rt_render_params *params, float *accum, rt_trace_stats *stats)
+{
+    if (!sc || !camera || !light || !params || !accum) return fail(RT_ERR_INVALID, "rt_render: NULL argument");
+    int rc = check_params(params, "rt_render");
+    if (rc != RT_OK) return rc;
+    rt_ctx *ctx = sc->ctx;
+    rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    size_t bytes = (size_t)params->width * params->height * 4 * sizeof(float);
+    rc = ctx->io_a.ensure(bytes);
+    if (rc != RT_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, accum, bytes, hipMemcpyHostToDevice, s));
+    rc = rt_render_device(sc, camera, light, params, (float *)ctx->io_a.p, stats, s);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(accum, ctx->io_a.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+extern "C" int rt_generate_primary(rt_ctx *ctx, const rt_camera *camera, const rt_render_params *params,
+                                   rt_stream_ray *rays)
+{
+    if (!ctx || !camera || !params || !rays) return fail(RT_ERR_INVALID, "rt_generate_primary: NULL argument");
+    int rc = check_params(params, "rt_generate_primary");
+    if (rc != RT_OK) return rc;
+    rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    unsigned long long total = (unsigned long long)params->width * params->height * params->samples;
+    if (total == 0) return RT_OK;
+    if (total > (1ull << 31)) return fail(RT_ERR_LIMIT, "rt_generate_primary: %llu rays exceed 2^31", total);
+    rc = ctx->io_a.ensure(total * sizeof(rt_stream_ray));
+    if (rc != RT_OK) return rc;
+    PassDev ps{};
+    ps.width = params->width;
+    ps.height = params->height;
+    ps.tile_size = params->tile_size;
+    ps.samples_this_pass = params->samples;
+    ps.sample_base = params->sample_offset;
+    ps.seed_key = seed_key_of(params->seed);
+    CameraDev cam = make_camera(*camera, params->width, params->height);
+    hipStream_t s = ctx->stream;
+    launch_generate_stream(cam, ps, (rt_stream_ray_dev *)ctx->io_a.p, total, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rays, ctx->io_a.p, total * sizeof(rt_stream_ray), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+extern "C" int rt_resolve(rt_ctx *ctx, const float *accum, uint32_t width, uint32_t height, uint8_t *rgb)
+{
+    if (!ctx || !accum || !rgb) return fail(RT_ERR_INVALID, "rt_resolve: NULL argument");
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    unsigned long long npix = (unsigned long long)width * height;
+    if (npix == 0) return RT_OK;
+    rc = ctx->io_a.ensure(npix * 4 * sizeof(float));
+    if (rc == RT_OK) rc = ctx->io_b.ensure(npix * 3);
+    if (rc != RT_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, accum, npix * 4 * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_resolve((const float *)ctx->io_a.p, npix, (unsigned char *)ctx->io_b.p, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb, ctx->io_b.p, npix * 3, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RT_OK;
+}

@@ -1,0 +1,40 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The CPU oracle binding (test infrastructure)."""
+    import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def rt():
+    """The product binding (librtcore.so through its C ABI)."""
+    return importlib.import_module("rust-raytracer_amd")
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    return importlib.import_module("rust-raytracer_amd.scenes")
+
+
+@pytest.fixture(scope="session")
+def ctx(rt):
+    c = rt.Context(0)
+    yield c
+    c.close()
