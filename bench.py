@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the MI355X ray-tracing core.
+
+A step is one pass of the hot path over one batch of synthetic input: the
+1920x1080 frame of the workload at `--spp` samples per pixel through generate /
+extend / shade / connect / accumulate, plus (N > 1) the RCCL sum-reduce of the
+float4 accumulation buffer to rank 0.  Scene, BVH and all queues are resident
+in HBM before the timed region.  Ranks render disjoint sample ranges of the same
+frame with full scene replicas (weak scaling: per-GPU work is fixed).
+
+Metric: Mrays/s = TraceStats.total_rays / 1e6 / seconds, counting every primary,
+bounce and shadow ray (src/trace_stats.rs:28-30, src/main.rs:175).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: Sponza primary + shadow rays only on one MI355X
+    "sponza-class": dict(scene="sponza-class", kw={}, bounces=0),
+    # configs[2]: high-poly mesh, diffuse path tracing
+    "dragon-class": dict(scene="dragon-class", kw={}, bounces=2),
+    # configs[3]: San Miguel full path tracing
+    "san-miguel-class": dict(scene="san-miguel-class", kw={}, bounces=2),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
+
+
+def extend_bytes_per_ray(st):
+    """Algorithmic bytes per closest-hit ray: 48 (StreamRay read) + 16 (hit
+    record) + 64 per inner-node visit + 48 per triangle test."""
+    n = max(1, st["total_rays"])
+    return 48.0 + 16.0 + 64.0 * st["inner_rays"] / n + 48.0 * st["obj_intersect"] / n
+
+
+def connect_bytes_per_ray(st):
+    n = max(1, st["total_rays"])
+    return 48.0 + 16.0 + 64.0 * st["inner_rays"] / n + 48.0 * st["obj_intersect"] / n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sponza-class", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=None)
+    ap.add_argument("--scene-scale", type=float, default=None, help="shrink the stand-in scene (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    n_gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    rt = importlib.import_module("rust-raytracer_amd")  # raises if librtcore.so is missing
+    scenes = importlib.import_module("rust-raytracer_amd.scenes")
+
+    wl = WORKLOADS[args.workload]
+    kw = dict(wl["kw"])
+    if args.scene_scale is not None:  # debug: smaller stand-in
+        if args.workload == "san-miguel-class":
+            kw["scale"] = args.scene_scale
+        elif args.workload == "sponza-class":
+            kw["detail"] = args.scene_scale
+        else:
+            kw["n"] = max(8, int(1900 * args.scene_scale ** 0.5))
+    bounces = wl["bounces"] if args.bounces is None else args.bounces
+    sc = scenes.load(wl["scene"], **kw)
+    W, H, S = args.width, args.height, args.spp
+
+    ctx = rt.Context(local_rank)
+    t0 = time.time()
+    scene = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+    build_s = time.time() - t0
+
+    step_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    total_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i, visit_stats=False):
+        step_accum.zero_()
+        st = scene.render_device(sc.camera, sc.light, step_accum.data_ptr(), W, H, S, max_bounces=bounces,
+                                 sample_offset=(i * n_gpus + rank) * S, stream=stream, stats=True,
+                                 visit_stats=visit_stats)
+        if world > 1:
+            dist.reduce(step_accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            total_accum.add_(step_accum)
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # counters for the roofline (un-timed, same workload)
+    step(0, visit_stats=True)
+    ext_st, con_st = ctx.last_stats_split()
+    total_accum.zero_()
+    for i in range(args.warmup):
+        step(i)
+    total_accum.zero_()
+
+    barrier()
+    t_start = time.perf_counter()
+    rays = 0
+    ms = {"extend": 0.0, "connect": 0.0, "other": 0.0}
+    launches = {"extend": 0, "connect": 0, "other": 0}
+    ext_rays = con_rays = 0
+    for i in range(args.steps):
+        st = step(i)
+        rays += st["total_rays"]
+        m, l = ctx.last_kernel_ms()
+        e, c = ctx.last_stats_split()
+        ext_rays += e["total_rays"]
+        con_rays += c["total_rays"]
+        for k in ms:
+            ms[k] += m[k]
+            launches[k] += l[k]
+    barrier()
+    elapsed = time.perf_counter() - t_start
+
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays_all = float(t[1])
+    else:
+        rays_all = float(rays)
+
+    if rank == 0:
+        value = rays_all / 1e6 / elapsed
+        b_ext = extend_bytes_per_ray(ext_st)
+        b_con = connect_bytes_per_ray(con_st)
+        ext_avg_ms = ms["extend"] / max(1, launches["extend"])
+        ext_rays_per_launch = ext_rays / max(1, launches["extend"])
+        achieved = b_ext * ext_rays_per_launch / (ext_avg_ms * 1e-3) / 1e9 if ext_avg_ms > 0 else 0.0
+        con_avg_ms = ms["connect"] / max(1, launches["connect"])
+        con_rays_per_launch = con_rays / max(1, launches["connect"])
+        con_ach = b_con * con_rays_per_launch / (con_avg_ms * 1e-3) / 1e9 if con_avg_ms > 0 else 0.0
+        img = total_accum.cpu().numpy()
+        out = {
+            "metric": "Mrays/s (primary+secondary+shadow rays, whole job)",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s stand-in (%d triangles, procedural), %dx%d, %d spp per step per GPU, "
+                            "max_bounces %d%s, tile 16, sample-range sharding + RCCL reduce" % (
+                                args.workload, sc.num_triangles, W, H, S, bounces,
+                                " (primary + shadow rays)" if bounces == 0 else ""),
+                "triangles": sc.num_triangles,
+                "bvh_build_s": round(build_s, 3),
+                "rays_per_step_per_gpu": int(rays / max(1, args.steps)),
+                "mean_pixel": float(img[..., :3].sum() / max(1.0, float(img[..., 3].sum()))),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "extend_kernel (closest-hit traversal)",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "bytes_per_ray": round(b_ext, 1),
+                "rays_per_launch": int(ext_rays_per_launch),
+                "avg_launch_ms": round(ext_avg_ms, 4),
+                "launches": launches["extend"],
+                "mrays_per_s": round(ext_rays_per_launch / (ext_avg_ms * 1e-3) / 1e6, 1) if ext_avg_ms > 0 else 0.0,
+                "inner_visits_per_ray": round(ext_st["inner_rays"] / max(1, ext_st["total_rays"]), 2),
+                "tri_tests_per_ray": round(ext_st["obj_intersect"] / max(1, ext_st["total_rays"]), 2),
+            },
+            "kernels": {
+                "connect": {"achieved_gbs": round(con_ach, 1), "bytes_per_ray": round(b_con, 1),
+                            "avg_launch_ms": round(con_avg_ms, 4), "launches": launches["connect"],
+                            "mrays_per_s": round(con_rays_per_launch / (con_avg_ms * 1e-3) / 1e6, 1) if con_avg_ms > 0 else 0.0,
+                            "inner_visits_per_ray": round(con_st["inner_rays"] / max(1, con_st["total_rays"]), 2),
+                            "tri_tests_per_ray": round(con_st["obj_intersect"] / max(1, con_st["total_rays"]), 2)},
+                "other_ms_per_step": round(ms["other"] / max(1, args.steps), 4),
+                "extend_ms_per_step": round(ms["extend"] / max(1, args.steps), 4),
+                "connect_ms_per_step": round(ms["connect"] / max(1, args.steps), 4),
+            },
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, W, H, bounces, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, W, H, bounces, budget_s):
+    """The CPU oracle (C restatement of the reference's default integrator,
+    integrate_tile_stream_shadow_immediate, tile-parallel like src/main.rs:157-161)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O  # checker / baseline only
+    threads = min(os.cpu_count() or 1, 16)
+    So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+    t0 = time.perf_counter()
+    _, st = So.render(sc.camera, sc.light, W, H, 1, max_bounces=bounces, nthreads=threads)
+    dt = time.perf_counter() - t0
+    spp = 1
+    rays, secs = st["total_rays"], dt
+    more = int(min(64, max(0, (budget_s - dt) // max(dt, 1e-3))))
+    if more >= 1:
+        t0 = time.perf_counter()
+        _, st = So.render(sc.camera, sc.light, W, H, more, max_bounces=bounces, sample_offset=1, nthreads=threads)
+        secs = time.perf_counter() - t0
+        rays, spp = st["total_rays"], more
+    return {"value": round(rays / 1e6 / secs, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "same scene, camera and bounce cap, %dx%d at %d spp (%.1f s of CPU work); C restatement of the "
+                      "reference's default integrator, not the Rust binary" % (W, H, spp, secs)}
+
+
+if __name__ == "__main__":
+    main()

@@ -219,6 +219,12 @@ int rt_resolve(rt_ctx *ctx, const float *accum, uint32_t width, uint32_t height,
  * events are synchronised by this call. */
 int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches[3]);
 
+/* Counters of the most recent trace or render call that asked for statistics,
+ * split by traversal kind: out[0] closest-hit (extend) launches, out[1]
+ * any-hit (connect) launches.  Their sum is what that call added to its
+ * rt_trace_stats argument (src/trace_stats.rs keeps one total only). */
+int rt_ctx_last_stats_split(rt_ctx *ctx, rt_trace_stats out[2]);
+
 #ifdef __cplusplus
 }
 #endif

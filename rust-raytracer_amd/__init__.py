@@ -94,6 +94,7 @@ EXPORTS = {
     "rt_ctx_destroy": (None, [_vp]),
     "rt_ctx_set_max_paths": (C.c_int, [_vp, C.c_uint64]),
     "rt_ctx_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint32 * 3)]),
+    "rt_ctx_last_stats_split": (C.c_int, [_vp, C.POINTER(TraceStats * 2)]),
     "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
     "rt_bvh_build_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
@@ -202,6 +203,12 @@ class Context:
         _check(_lib.rt_ctx_last_kernel_ms(self.h, C.byref(ms), C.byref(ln)))
         names = ("extend", "connect", "other")
         return {n: float(ms[i]) for i, n in enumerate(names)}, {n: int(ln[i]) for i, n in enumerate(names)}
+
+    def last_stats_split(self):
+        """Counters of the last call with statistics: (closest-hit, any-hit)."""
+        out = (TraceStats * 2)()
+        _check(_lib.rt_ctx_last_stats_split(self.h, C.byref(out)))
+        return out[0].as_dict(), out[1].as_dict()
 
     def generate_primary(self, cam, width, height, samples, tile_size=16, seed=1235468, sample_offset=0):
         p = RenderParams(width, height, samples, sample_offset, 0, tile_size, 0, 1, 0, 0, seed)

@@ -104,6 +104,7 @@ struct rt_ctx {
     std::vector<TimedLaunch> pool;
     size_t used = 0;
     bool timing = true;
+    rt_trace_stats last_split[2]{}; // [0] closest-hit launches, [1] any-hit launches of the last call with stats
 };
 
 struct rt_scene {
@@ -182,7 +183,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
         delete ctx;
         return fail(RT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    int rc = ctx->dstats.ensure(sizeof(StatsDev));
+    int rc = ctx->dstats.ensure(2 * sizeof(StatsDev));
     if (rc == RT_OK) rc = ensure_overflow(ctx, 0);
     if (rc != RT_OK) {
         rt_ctx_destroy(ctx);
@@ -239,6 +240,14 @@ extern "C" int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches
         ms[t.kind] += v;
         launches[t.kind] += 1;
     }
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_last_stats_split(rt_ctx *ctx, rt_trace_stats out[2])
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_stats_split: NULL argument");
+    out[0] = ctx->last_split[0];
+    out[1] = ctx->last_split[1];
     return RT_OK;
 }
 
@@ -460,20 +469,24 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     rt_ctx *ctx = sc->ctx;
     ctx->used = 0;
     bool want = stats != nullptr;
-    if (want) HIP_TRY(hipMemsetAsync(ctx->dstats.p, 0, sizeof(StatsDev), s));
+    if (want) HIP_TRY(hipMemsetAsync(ctx->dstats.p, 0, 2 * sizeof(StatsDev), s));
     size_t slot;
     int rc = timed_begin(ctx, anyhit ? 1 : 0, s, &slot);
     if (rc != RT_OK) return rc;
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, (unsigned *)ctx->ovf.p,
-                        (StatsDev *)ctx->dstats.p, ctx->max_blocks, s);
+                        (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0), ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
     rc = timed_end(ctx, slot, s);
     if (rc != RT_OK) return rc;
     if (want && sync_stats) {
-        StatsDev h{};
-        HIP_TRY(hipMemcpyAsync(&h, ctx->dstats.p, sizeof h, hipMemcpyDeviceToHost, s));
+        StatsDev h[2]{};
+        HIP_TRY(hipMemcpyAsync(h, ctx->dstats.p, sizeof h, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        stats_from_dev(h, stats);
+        for (int k = 0; k < 2; k++) {
+            ctx->last_split[k] = rt_trace_stats{};
+            stats_from_dev(h[k], &ctx->last_split[k]);
+            stats_from_dev(h[k], stats);
+        }
     }
     return RT_OK;
 }
@@ -694,8 +707,8 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
     const uint32_t seed_key = seed_key_of(params->seed);
     const bool want = stats != nullptr;
     const bool visit = want && (params->flags & RT_RENDER_VISIT_STATS);
-    StatsDev *dstats = (StatsDev *)ctx->dstats.p;
-    if (want) HIP_TRY(hipMemsetAsync(dstats, 0, sizeof(StatsDev), s));
+    StatsDev *dstats = (StatsDev *)ctx->dstats.p; // [0] extend, [1] connect
+    if (want) HIP_TRY(hipMemsetAsync(dstats, 0, 2 * sizeof(StatsDev), s));
 
     float *rad_r = (float *)w.rad.p, *rad_g = rad_r + slots, *rad_b = rad_g + slots;
     uint32_t *counters = (uint32_t *)w.counters.p;
@@ -764,10 +777,10 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
-                               &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, ovf, dstats, ctx->max_blocks, s);
+                               &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, ovf, dstats + 1, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
-                if (want && !visit) launch_count_rays(&n_sh[b], dstats, s);
+                if (want && !visit) launch_count_rays(&n_sh[b], dstats + 1, s);
                 cur ^= 1;
             }
             rc = timed_begin(ctx, 2, s, &slot);
@@ -779,13 +792,18 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
         }
     }
     if (want) {
-        StatsDev h{};
-        HIP_TRY(hipMemcpyAsync(&h, dstats, sizeof h, hipMemcpyDeviceToHost, s));
+        StatsDev h[2]{};
+        HIP_TRY(hipMemcpyAsync(h, dstats, sizeof h, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (visit) {
-            stats_from_dev(h, stats);
-        } else {
-            stats->total_rays += h.total_rays;
+        for (int q = 0; q < 2; q++) {
+            ctx->last_split[q] = rt_trace_stats{};
+            if (visit) {
+                stats_from_dev(h[q], &ctx->last_split[q]);
+                stats_from_dev(h[q], stats);
+            } else {
+                ctx->last_split[q].total_rays = h[q].total_rays;
+                stats->total_rays += h[q].total_rays;
+            }
         }
     }
     return RT_OK;
