@@ -72,6 +72,59 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
+// Block-aggregated queue append.  A global counter takes about 88 M atomics/s
+// on one word, so one atomic per wave (260 K per 16 M-ray launch) costs
+// milliseconds; here a block of NW waves with ITEMS items per thread and NQ
+// output queues makes NQ atomics in total.  Entry e = (q*ITEMS + it)*NW + wave
+// of `lds` (NQ*ITEMS*NW <= 64 entries) first holds the wave's count for item
+// `it` of queue q, afterwards the queue position of that wave's first element.
+template <int NW, int ITEMS, int NQ>
+__device__ __forceinline__ void block_reserve(const bool (&pred)[NQ][ITEMS], unsigned *const (&counters)[NQ],
+                                              unsigned (&pos)[NQ][ITEMS], unsigned *lds)
+{
+    static_assert(NQ * ITEMS * NW <= 64, "one wave scans all entries");
+    const unsigned wave = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    unsigned pre[NQ][ITEMS];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+            const unsigned long long mask = __ballot(pred[q][it]);
+            pre[q][it] = prefix_count(mask);
+            if (lane == 0) lds[(q * ITEMS + it) * NW + wave] = (unsigned)__popcll(mask);
+        }
+    __syncthreads();
+    if (wave == 0) {
+        constexpr int E = NQ * ITEMS * NW;
+        const unsigned mine = lane < E ? lds[lane] : 0u;
+        const unsigned q_of = lane / (ITEMS * NW); // queue of this entry
+        // inclusive scan within each queue's run of ITEMS*NW entries
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < ITEMS * NW; off <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, off);
+            if ((lane % (ITEMS * NW)) >= (unsigned)off) incl += up;
+        }
+        // last entry of each queue holds that queue's total
+        unsigned base = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const unsigned total = (unsigned)__shfl((int)incl, (q + 1) * ITEMS * NW - 1);
+            unsigned b = 0;
+            if (lane == 0 && total != 0) b = atomicAdd(counters[q], total);
+            b = (unsigned)__shfl((int)b, 0);
+            if (q_of == (unsigned)q) base = b;
+        }
+        if (lane < E) lds[lane] = base + incl - mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) pos[q][it] = lds[(q * ITEMS + it) * NW + wave] + pre[q][it];
+}
+
 // ------------------------------------------------------------------------
 // traversal core
 
@@ -484,56 +537,80 @@ __device__ __forceinline__ V3 camera_sample(const CameraDev &cam, V3 pixel_ray, 
     return normalize(pixel_ray + off);
 }
 
-// One thread per path slot of the pass.  slot = ((tile_local*ts*ts + py*ts + px)
-// * k + s); tiles are the shard's tiles [tile_begin, tile_begin+tile_count).
-__global__ __launch_bounds__(256) void generate_kernel(CameraDev cam, PassDev ps, QRay *rays, PathInfo *infos,
-                                                      unsigned *n_out, float *rad_r, float *rad_g,
-                                                      float *rad_b)
+// Path slots of the pass: slot = ((tile_local*ts*ts + py*ts + px) * k + s);
+// tiles are the shard's tiles [tile_begin, tile_begin+tile_count).  A block
+// covers kGenItems*256 consecutive slots; slots outside the image (partial edge
+// tiles) or beyond the pass's sample count produce no ray.
+constexpr int kGenItems = 8;
+constexpr int kGenBlock = 512;
+
+__device__ __forceinline__ bool slot_to_pixel(const PassDev &ps, unsigned slot, unsigned &x, unsigned &y,
+                                              unsigned &s)
 {
-    const unsigned slot = blockIdx.x * 256u + threadIdx.x;
-    bool valid = slot < ps.num_slots;
-    unsigned x = 0, y = 0, s = 0;
-    if (valid) {
-        const unsigned k = ps.samples_per_pass;
-        const unsigned ts2 = ps.tile_size * ps.tile_size;
-        s = slot % k;
-        const unsigned p = slot / k;
-        const unsigned pin = p % ts2;
-        const unsigned tl = p / ts2;
-        const unsigned tile = ps.shard_index + (ps.tile_begin + tl) * ps.shard_count;
-        const unsigned tx = tile % ps.tiles_x, ty = tile / ps.tiles_x;
-        x = tx * ps.tile_size + pin % ps.tile_size;
-        y = ty * ps.tile_size + pin / ps.tile_size;
-        rad_r[slot] = 0.f;
-        rad_g[slot] = 0.f;
-        rad_b[slot] = 0.f;
-        valid = (x < ps.width) && (y < ps.height) && (s < ps.samples_this_pass);
+    if (slot >= ps.num_slots) return false;
+    const unsigned k = ps.samples_per_pass;
+    const unsigned ts2 = ps.tile_size * ps.tile_size;
+    s = slot % k;
+    const unsigned p = slot / k;
+    const unsigned pin = p % ts2;
+    const unsigned tl = p / ts2;
+    const unsigned tile = ps.shard_index + (ps.tile_begin + tl) * ps.shard_count;
+    const unsigned tx = tile % ps.tiles_x, ty = tile / ps.tiles_x;
+    x = tx * ps.tile_size + pin % ps.tile_size;
+    y = ty * ps.tile_size + pin / ps.tile_size;
+    return (x < ps.width) && (y < ps.height) && (s < ps.samples_this_pass);
+}
+
+__global__ __launch_bounds__(kGenBlock) void generate_kernel(CameraDev cam, PassDev ps, QRay *rays,
+                                                            PathInfo *infos, unsigned *n_out, float *rad_r,
+                                                            float *rad_g, float *rad_b)
+{
+    __shared__ unsigned lds[64];
+    const unsigned block_base = blockIdx.x * (unsigned)(kGenBlock * kGenItems);
+    bool pred[1][kGenItems];
+    unsigned pos[1][kGenItems];
+#pragma unroll
+    for (int it = 0; it < kGenItems; it++) {
+        unsigned x, y, sidx;
+        pred[0][it] = slot_to_pixel(ps, block_base + it * kGenBlock + threadIdx.x, x, y, sidx);
     }
-    const unsigned idx = queue_reserve(valid, n_out);
-    if (!valid) return;
-    const unsigned pixel = y * ps.width + x;
-    const unsigned gs = ps.sample_base + s;
-    const unsigned key = rng_key(ps.seed_key, pixel, gs);
-    const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
-    const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
-    QRay q;
-    q.o[0] = cam.eye[0];
-    q.o[1] = cam.eye[1];
-    q.o[2] = cam.eye[2];
-    q.near_t = 0.f;
-    q.d[0] = d.x;
-    q.d[1] = d.y;
-    q.d[2] = d.z;
-    q.far_t = __builtin_inff();
-    rays[idx] = q;
-    PathInfo pi;
-    pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
-    pi.slot = slot;
-    pi.pixel = pixel;
-    pi.sample = gs;
-    pi.bounces = 0;
-    pi.pad = 0;
-    infos[idx] = pi;
+    unsigned *const counters[1] = {n_out};
+    block_reserve<kGenBlock / 64, kGenItems, 1>(pred, counters, pos, lds);
+#pragma unroll
+    for (int it = 0; it < kGenItems; it++) {
+        const unsigned slot = block_base + it * kGenBlock + threadIdx.x;
+        if (slot < ps.num_slots) {
+            rad_r[slot] = 0.f;
+            rad_g[slot] = 0.f;
+            rad_b[slot] = 0.f;
+        }
+        unsigned x, y, sidx;
+        if (!slot_to_pixel(ps, slot, x, y, sidx)) continue;
+        const unsigned idx = pos[0][it];
+        const unsigned pixel = y * ps.width + x;
+        const unsigned gs = ps.sample_base + sidx;
+        const unsigned key = rng_key(ps.seed_key, pixel, gs);
+        const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
+        const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
+        QRay q;
+        q.o[0] = cam.eye[0];
+        q.o[1] = cam.eye[1];
+        q.o[2] = cam.eye[2];
+        q.near_t = 0.f;
+        q.d[0] = d.x;
+        q.d[1] = d.y;
+        q.d[2] = d.z;
+        q.far_t = __builtin_inff();
+        rays[idx] = q;
+        PathInfo pi;
+        pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
+        pi.slot = slot;
+        pi.pixel = pixel;
+        pi.sample = gs;
+        pi.bounces = 0;
+        pi.pad = 0;
+        infos[idx] = pi;
+    }
 }
 
 // Primary rays of the whole frame as StreamRays in (pixel, sample) order.
@@ -560,91 +637,112 @@ __global__ __launch_bounds__(256) void generate_stream_kernel(CameraDev cam, Pas
 // shade: loop body of integrate_tile_stream
 // (src/integrators/integrate_stream.rs:104-138) for every ray of the queue.
 
-__global__ __launch_bounds__(256) void shade_kernel(ShadeArgs a)
-{
-    const unsigned n = *a.n_in;
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    bool has_shadow = false, has_bounce = false;
+struct ShadeOut {
     QRay sh_ray, bn_ray;
     ShadowInfo sh_info;
     PathInfo bn_info;
-    if (i < n) {
-        const unsigned id = a.hit_ids[i];
-        if (id != 0xFFFFFFFFu) {
-            const QRay ray = a.rays_in[i];
-            const PathInfo info = a.infos_in[i];
-            const V3 o = v3(ray.o[0], ray.o[1], ray.o[2]);
-            const V3 d = v3(ray.d[0], ray.d[1], ray.d[2]);
-            const V3 hp = o + scale(d, ray.far_t); // src/ray.rs:40-42
-            const V3 wo = -d;
-            const float4 n4 = reinterpret_cast<const float4 *>(a.normals)[id];
-            const V3 nrm = v3(n4.x, n4.y, n4.z);
-            const V3 pw = v3(info.w[0], info.w[1], info.w[2]);
+};
 
-            // sample_light, src/integrators/common.rs:37-60
-            {
-                const V3 lv = v3(a.light_pos[0], a.light_pos[1], a.light_pos[2]) - hp;
-                float ndotl = dot(nrm, lv);
-                if (!(ndotl * dot(nrm, wo) < 0.f)) {
-                    const float d2 = dot(lv, lv);
-                    const float dist = sqrtf(d2);
-                    const V3 wi = divs(lv, dist);
-                    ndotl = fabsf(ndotl / dist);
-                    const float f = 0.8f / 3.14159274f; // src/brdf.rs:24-26
-                    const V3 li = v3(a.light_intensity[0], a.light_intensity[1], a.light_intensity[2]);
-                    const V3 w = divs(scale(mul(li, v3(f, f, f)), ndotl), d2);
-                    if (!(w.x == 0.f && w.y == 0.f && w.z == 0.f)) {
-                        has_shadow = true;
-                        sh_ray.o[0] = hp.x; sh_ray.o[1] = hp.y; sh_ray.o[2] = hp.z;
-                        sh_ray.near_t = 1e-5f; // SHADOW_RAY_NEAR, common.rs:12
-                        sh_ray.d[0] = wi.x; sh_ray.d[1] = wi.y; sh_ray.d[2] = wi.z;
-                        sh_ray.far_t = dist;
-                        const V3 c = mul(pw, w);
-                        sh_info.w[0] = c.x; sh_info.w[1] = c.y; sh_info.w[2] = c.z;
-                        sh_info.slot = info.slot;
-                    }
-                }
-            }
+__device__ __forceinline__ void shade_one(const ShadeArgs &a, unsigned i, unsigned n, bool &has_shadow,
+                                          bool &has_bounce, ShadeOut &o)
+{
+    has_shadow = false;
+    has_bounce = false;
+    if (i >= n) return;
+    const unsigned id = a.hit_ids[i];
+    if (id == 0xFFFFFFFFu) return; // a miss contributes nothing and ends the path (integrate_stream.rs:105)
+    const QRay ray = a.rays_in[i];
+    const PathInfo info = a.infos_in[i];
+    const V3 org = v3(ray.o[0], ray.o[1], ray.o[2]);
+    const V3 d = v3(ray.d[0], ray.d[1], ray.d[2]);
+    const V3 hp = org + scale(d, ray.far_t); // src/ray.rs:40-42
+    const V3 wo = -d;
+    const float4 n4 = reinterpret_cast<const float4 *>(a.normals)[id];
+    const V3 nrm = v3(n4.x, n4.y, n4.z);
+    const V3 pw = v3(info.w[0], info.w[1], info.w[2]);
 
-            // sample_diffuse_ray, src/integrators/common.rs:64-78 + src/brdf.rs:10-17,36-44
-            if (info.bounces < a.max_bounces) {
-                const unsigned key = rng_key(a.seed_key, info.pixel, info.sample);
-                const float u0 = rng_f32(key, 2u + 2u * info.bounces);
-                const float u1 = rng_f32(key, 3u + 2u * info.bounces);
-                const Quat q = rotation_to_z(nrm);
-                const V3 wo_l = rotate(q, wo);
-                const float aa = sqrtf(u0);
-                float sn, cs;
-                sincos_2pi(u1, sn, cs);
-                V3 wi_l = v3(aa * cs, aa * sn, sqrtf(1.f - u0));
-                const float pdf = wi_l.z / 3.14159274f;
-                const float f = 0.8f / 3.14159274f;
-                wi_l.z = copysignf(wi_l.z, wo_l.z);
-                Quat qi = q;
-                qi.v = -q.v;
-                const V3 wi = rotate(qi, wi_l);
-                const float ndotl = fabsf(dot(nrm, wi));
-                const float w = f * ndotl / pdf;
-                has_bounce = true;
-                bn_ray.o[0] = hp.x; bn_ray.o[1] = hp.y; bn_ray.o[2] = hp.z;
-                bn_ray.near_t = 1e-5f;
-                bn_ray.d[0] = wi.x; bn_ray.d[1] = wi.y; bn_ray.d[2] = wi.z;
-                bn_ray.far_t = __builtin_inff();
-                bn_info = info;
-                bn_info.w[0] = pw.x * w; bn_info.w[1] = pw.y * w; bn_info.w[2] = pw.z * w;
-                bn_info.bounces = info.bounces + 1;
+    // sample_light, src/integrators/common.rs:37-60
+    {
+        const V3 lv = v3(a.light_pos[0], a.light_pos[1], a.light_pos[2]) - hp;
+        float ndotl = dot(nrm, lv);
+        if (!(ndotl * dot(nrm, wo) < 0.f)) {
+            const float d2 = dot(lv, lv);
+            const float dist = sqrtf(d2);
+            const V3 wi = divs(lv, dist);
+            ndotl = fabsf(ndotl / dist);
+            const float f = 0.8f / 3.14159274f; // src/brdf.rs:24-26
+            const V3 li = v3(a.light_intensity[0], a.light_intensity[1], a.light_intensity[2]);
+            const V3 w = divs(scale(mul(li, v3(f, f, f)), ndotl), d2);
+            if (!(w.x == 0.f && w.y == 0.f && w.z == 0.f)) {
+                has_shadow = true;
+                o.sh_ray.o[0] = hp.x; o.sh_ray.o[1] = hp.y; o.sh_ray.o[2] = hp.z;
+                o.sh_ray.near_t = 1e-5f; // SHADOW_RAY_NEAR, common.rs:12
+                o.sh_ray.d[0] = wi.x; o.sh_ray.d[1] = wi.y; o.sh_ray.d[2] = wi.z;
+                o.sh_ray.far_t = dist;
+                const V3 c = mul(pw, w);
+                o.sh_info.w[0] = c.x; o.sh_info.w[1] = c.y; o.sh_info.w[2] = c.z;
+                o.sh_info.slot = info.slot;
             }
         }
     }
-    const unsigned si = queue_reserve(has_shadow, a.n_shadow);
-    if (has_shadow) {
-        a.shadow_rays[si] = sh_ray;
-        a.shadow_infos[si] = sh_info;
+
+    // sample_diffuse_ray, src/integrators/common.rs:64-78 + src/brdf.rs:10-17,36-44
+    if (info.bounces < a.max_bounces) {
+        const unsigned key = rng_key(a.seed_key, info.pixel, info.sample);
+        const float u0 = rng_f32(key, 2u + 2u * info.bounces);
+        const float u1 = rng_f32(key, 3u + 2u * info.bounces);
+        const Quat q = rotation_to_z(nrm);
+        const V3 wo_l = rotate(q, wo);
+        const float aa = sqrtf(u0);
+        float sn, cs;
+        sincos_2pi(u1, sn, cs);
+        V3 wi_l = v3(aa * cs, aa * sn, sqrtf(1.f - u0));
+        const float pdf = wi_l.z / 3.14159274f;
+        const float f = 0.8f / 3.14159274f;
+        wi_l.z = copysignf(wi_l.z, wo_l.z);
+        Quat qi = q;
+        qi.v = -q.v;
+        const V3 wi = rotate(qi, wi_l);
+        const float ndotl = fabsf(dot(nrm, wi));
+        const float w = f * ndotl / pdf;
+        has_bounce = true;
+        o.bn_ray.o[0] = hp.x; o.bn_ray.o[1] = hp.y; o.bn_ray.o[2] = hp.z;
+        o.bn_ray.near_t = 1e-5f;
+        o.bn_ray.d[0] = wi.x; o.bn_ray.d[1] = wi.y; o.bn_ray.d[2] = wi.z;
+        o.bn_ray.far_t = __builtin_inff();
+        o.bn_info = info;
+        o.bn_info.w[0] = pw.x * w; o.bn_info.w[1] = pw.y * w; o.bn_info.w[2] = pw.z * w;
+        o.bn_info.bounces = info.bounces + 1;
     }
-    const unsigned bi = queue_reserve(has_bounce, a.n_out);
-    if (has_bounce) {
-        a.rays_out[bi] = bn_ray;
-        a.infos_out[bi] = bn_info;
+}
+
+constexpr int kShadeBlock = 1024;
+constexpr int kShadeItems = 2;
+
+__global__ __launch_bounds__(kShadeBlock) void shade_kernel(ShadeArgs a)
+{
+    __shared__ unsigned lds[64];
+    const unsigned n = *a.n_in;
+    const unsigned block_base = blockIdx.x * (unsigned)(kShadeBlock * kShadeItems);
+    if (block_base >= n) return; // whole block past the queue (uniform)
+    bool pred[2][kShadeItems];
+    unsigned pos[2][kShadeItems];
+    ShadeOut out[kShadeItems];
+#pragma unroll
+    for (int it = 0; it < kShadeItems; it++)
+        shade_one(a, block_base + it * kShadeBlock + threadIdx.x, n, pred[0][it], pred[1][it], out[it]);
+    unsigned *const counters[2] = {a.n_shadow, a.n_out};
+    block_reserve<kShadeBlock / 64, kShadeItems, 2>(pred, counters, pos, lds);
+#pragma unroll
+    for (int it = 0; it < kShadeItems; it++) {
+        if (pred[0][it]) {
+            a.shadow_rays[pos[0][it]] = out[it].sh_ray;
+            a.shadow_infos[pos[0][it]] = out[it].sh_info;
+        }
+        if (pred[1][it]) {
+            a.rays_out[pos[1][it]] = out[it].bn_ray;
+            a.infos_out[pos[1][it]] = out[it].bn_info;
+        }
     }
 }
 
@@ -772,10 +870,11 @@ void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stre
 void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,
                      float *rad_r, float *rad_g, float *rad_b, hipStream_t stream)
 {
-    const unsigned grid = (ps.num_slots + 255u) / 256u;
+    const unsigned per_block = (unsigned)(kGenBlock * kGenItems);
+    const unsigned grid = (ps.num_slots + per_block - 1u) / per_block;
     if (grid == 0) return;
-    hipLaunchKernelGGL(generate_kernel, dim3(grid), dim3(256), 0, stream, cam, ps, rays, infos, n_out, rad_r,
-                       rad_g, rad_b);
+    hipLaunchKernelGGL(generate_kernel, dim3(grid), dim3(kGenBlock), 0, stream, cam, ps, rays, infos, n_out,
+                       rad_r, rad_g, rad_b);
 }
 
 void launch_generate_stream(const CameraDev &cam, const PassDev &ps, rt_stream_ray_dev *rays,
@@ -788,9 +887,10 @@ void launch_generate_stream(const CameraDev &cam, const PassDev &ps, rt_stream_r
 
 void launch_shade(const ShadeArgs &a, unsigned n_upper, hipStream_t stream)
 {
-    const unsigned grid = (n_upper + 255u) / 256u;
+    const unsigned per_block = (unsigned)(kShadeBlock * kShadeItems);
+    const unsigned grid = (n_upper + per_block - 1u) / per_block;
     if (grid == 0) return;
-    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(kShadeBlock), 0, stream, a);
 }
 
 void launch_accumulate(const PassDev &ps, const float *rad_r, const float *rad_g, const float *rad_b,
