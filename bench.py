@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--scene-scale", type=float, default=None, help="shrink the stand-in scene (debug)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--shard", default="sample", choices=["sample", "tile"],
+                    help="sample: every rank renders --spp samples of the whole frame per step (weak scaling); "
+                         "tile: the step's --spp samples are split by tile (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -72,14 +76,20 @@ def main():
     if world != args.gpus and world != 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     n_gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank; ranks wrap around only when a node is rehearsed on fewer GPUs (gloo)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     rt = importlib.import_module("rust-raytracer_amd")  # raises if librtcore.so is missing
     scenes = importlib.import_module("rust-raytracer_amd.scenes")
+    node = importlib.import_module("rust-raytracer_amd.node_render")
 
     wl = WORKLOADS[args.workload]
     kw = dict(wl["kw"])
@@ -94,7 +104,7 @@ def main():
     sc = scenes.load(wl["scene"], **kw)
     W, H, S = args.width, args.height, args.spp
 
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(dev_index)
     t0 = time.time()
     scene = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
     build_s = time.time() - t0
@@ -103,16 +113,24 @@ def main():
     total_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    frame_spp = S * n_gpus if args.shard == "sample" else S   # samples of the whole frame per step
+    last = {}
+
     def step(i, visit_stats=False):
         step_accum.zero_()
-        st = scene.render_device(sc.camera, sc.light, step_accum.data_ptr(), W, H, S, max_bounces=bounces,
-                                 sample_offset=(i * n_gpus + rank) * S, stream=stream, stats=True,
-                                 visit_stats=visit_stats)
-        if world > 1:
-            dist.reduce(step_accum, dst=0, op=dist.ReduceOp.SUM)
+
+        def render_fn(acc, samples, sample_offset, shard_index, shard_count):
+            st = scene.render_device(sc.camera, sc.light, acc.data_ptr(), W, H, samples, max_bounces=bounces,
+                                     sample_offset=sample_offset, shard_index=shard_index,
+                                     shard_count=shard_count, stream=stream, stats=True, visit_stats=visit_stats)
+            last["st"] = st
+            return st["total_rays"]
+
+        rays = node.node_render(render_fn, step_accum, rank, n_gpus, args.shard, frame_spp,
+                                sample_offset=i * frame_spp)
         if rank == 0:
             total_accum.add_(step_accum)
-        return st
+        return {"total_rays": rays}
 
     def barrier():
         if world > 1:
@@ -176,15 +194,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.shard == "sample" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "%s stand-in (%d triangles, procedural), %dx%d, %d spp per step per GPU, "
-                            "max_bounces %d%s, tile 16, sample-range sharding + RCCL reduce" % (
+                            "max_bounces %d%s, tile 16, %s sharding + sum-reduce of the accumulation buffer (%s)" % (
                                 args.workload, sc.num_triangles, W, H, S, bounces,
-                                " (primary + shadow rays)" if bounces == 0 else ""),
+                                " (primary + shadow rays)" if bounces == 0 else "", args.shard,
+                                args.backend if n_gpus > 1 else "single GPU"),
                 "triangles": sc.num_triangles,
                 "bvh_build_s": round(build_s, 3),
                 "rays_per_step_per_gpu": int(rays / max(1, args.steps)),

@@ -219,6 +219,11 @@ int rt_resolve(rt_ctx *ctx, const float *accum, uint32_t width, uint32_t height,
  * events are synchronised by this call. */
 int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches[3]);
 
+/* Per-launch form of rt_ctx_last_kernel_ms: the first min(cap, count) launches
+ * of the last call in issue order; kind[i] = 0 closest-hit, 1 any-hit,
+ * 2 other.  *count receives the total number of timed launches. */
+int rt_ctx_last_launch_ms(rt_ctx *ctx, float *ms, uint32_t *kind, uint32_t cap, uint32_t *count);
+
 /* Counters of the most recent trace or render call that asked for statistics,
  * split by traversal kind: out[0] closest-hit (extend) launches, out[1]
  * any-hit (connect) launches.  Their sum is what that call added to its

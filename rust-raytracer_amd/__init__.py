@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtcore.so")
+# RTCORE_LIB selects another build of the same library (tuning experiments)
+LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(_HERE, "librtcore.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rtcore.h")
 
 NO_HIT = 0xFFFFFFFF
@@ -94,6 +95,7 @@ EXPORTS = {
     "rt_ctx_destroy": (None, [_vp]),
     "rt_ctx_set_max_paths": (C.c_int, [_vp, C.c_uint64]),
     "rt_ctx_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint32 * 3)]),
+    "rt_ctx_last_launch_ms": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rt_ctx_last_stats_split": (C.c_int, [_vp, C.POINTER(TraceStats * 2)]),
     "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
@@ -203,6 +205,16 @@ class Context:
         _check(_lib.rt_ctx_last_kernel_ms(self.h, C.byref(ms), C.byref(ln)))
         names = ("extend", "connect", "other")
         return {n: float(ms[i]) for i, n in enumerate(names)}, {n: int(ln[i]) for i, n in enumerate(names)}
+
+    def last_launch_ms(self, cap=4096):
+        """[(kind, ms)] of the last call's timed launches in issue order; kind is
+        'extend', 'connect' or 'other'."""
+        ms = np.zeros(cap, np.float32)
+        kind = np.zeros(cap, np.uint32)
+        n = C.c_uint32()
+        _check(_lib.rt_ctx_last_launch_ms(self.h, _p(ms), _p(kind), cap, C.byref(n)))
+        names = ("extend", "connect", "other")
+        return [(names[int(kind[i])], float(ms[i])) for i in range(min(cap, n.value))]
 
     def last_stats_split(self):
         """Counters of the last call with statistics: (closest-hit, any-hit)."""

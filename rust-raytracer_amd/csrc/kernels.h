@@ -13,7 +13,27 @@
 #define RTC_LDS_STACK_DEPTH 24
 #endif
 
+// occupancy the trace kernels are compiled for (waves per SIMD): bounds the
+// VGPR allocation; together with the LDS stack it sets resident blocks per CU
+#ifndef RTC_TRACE_WAVES_PER_SIMD
+#define RTC_TRACE_WAVES_PER_SIMD 6
+#endif
+
 namespace rtc {
+
+// Ray-fetch counters of one trace launch: kFetchRanges counters, each alone in
+// a 128-byte line.
+constexpr unsigned kFetchRanges = 32;
+constexpr unsigned kFetchStride = 32; // uints between counters
+constexpr unsigned kFetchUints = kFetchRanges * kFetchStride;
+
+struct TraceLaunch {
+    unsigned *fetch;     // kFetchUints uints, zeroed before the launch
+    unsigned *ovf;       // traversal stack overflow area
+    StatsDev *stats;
+    unsigned min_active; // a wave refills when fewer lanes than this are traversing (1..64)
+    unsigned mode;       // 0 = while-while loop, 1 = one item (node or triangle) per iteration
+};
 
 // StreamRay (src/ray.rs:6-12) as three float4.
 struct alignas(16) rt_stream_ray_dev {
@@ -66,13 +86,13 @@ struct ShadeArgs {
 };
 
 void launch_trace_stream(bool anyhit, bool stats, const SceneDev &sc, rt_stream_ray_dev *rays, unsigned *hits,
-                         unsigned char *occluded, unsigned n, unsigned *ovf, StatsDev *dstats,
-                         unsigned max_blocks, hipStream_t stream);
+                         unsigned char *occluded, unsigned n, const TraceLaunch &tl, unsigned max_blocks,
+                         hipStream_t stream);
 void launch_extend(bool stats, const SceneDev &sc, QRay *rays, unsigned *hit_ids, const unsigned *n_ptr,
-                   unsigned n_upper, unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream);
+                   unsigned n_upper, const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream);
 void launch_connect(bool stats, const SceneDev &sc, const QRay *rays, const ShadowInfo *infos,
                     const unsigned *n_ptr, unsigned n_upper, float *rad_r, float *rad_g, float *rad_b,
-                    unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream);
+                    const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream);
 void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream);
 void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,
                      float *rad_r, float *rad_g, float *rad_b, hipStream_t stream);

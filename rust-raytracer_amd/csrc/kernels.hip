@@ -183,7 +183,8 @@ __device__ __forceinline__ float tri_test(const float4 t0, const float4 t1, cons
     return ok ? t : __builtin_inff();
 }
 
-// One ray through the tree.
+// Traversal of one ray per lane, written as a resumable per-lane state machine
+// so that a wave can replace finished rays while the others keep going.
 //
 // ANYHIT = false: Bvh::intersect_stream seen from one ray
 // (src/bvh/intersect_stream.rs:67-181): at an inner node both children are
@@ -193,27 +194,51 @@ __device__ __forceinline__ float tri_test(const float4 t0, const float4 t1, cons
 // shrink far (418-422).
 //
 // ANYHIT = true: Bvh::occluded1 (src/bvh/intersect1.rs:7-106): left child
-// first, far fixed, return at the first accepted triangle.
+// first, far fixed, done at the first accepted triangle.
 //
 // NaN: bb*inf - o*inf can be NaN.  v_max_f32 / v_min_f32 ignore a NaN operand,
 // which drops that slab constraint (more visits, never a missed hit), like the
 // reference's operand order does on x86.
+struct LaneState {
+    RayRegs r;
+    float ordx, ordy, ordz; // o * (1/d), rounded once per ray (intersect_stream.rs:112-114)
+    bool negx, negy, negz;  // sign bit of 1/d (blendv, intersect_stream.rs:116-121)
+    unsigned cur;           // node reference being visited, kDone when idle
+    unsigned tri, tri_end;  // triangle cursor inside the current leaf (stepwise traversal)
+    unsigned hit;           // closest: mesh triangle id or ~0u; any-hit: 1 when occluded
+    unsigned index;         // position of the ray in its queue
+    bool have_ray;
+};
+
+__device__ __forceinline__ void lane_begin(LaneState &s, const SceneDev &sc, const RayRegs &r, unsigned index)
+{
+    s.r = r;
+    s.negx = (__float_as_uint(r.rd.x) >> 31) != 0;
+    s.negy = (__float_as_uint(r.rd.y) >> 31) != 0;
+    s.negz = (__float_as_uint(r.rd.z) >> 31) != 0;
+    s.ordx = r.o.x * r.rd.x;
+    s.ordy = r.o.y * r.rd.y;
+    s.ordz = r.o.z * r.rd.z;
+    s.cur = sc.root_ref;
+    s.tri = s.tri_end = 0;
+    s.hit = 0xFFFFFFFFu;
+    s.index = index;
+    s.have_ray = true;
+}
+
+// Runs the lane's ray until it is done (s.cur == kDone) or until fewer than
+// `min_active` lanes of the wave are still traversing (the wave then goes back
+// to fetch rays for its idle lanes).
 template <bool ANYHIT, bool STATS, class STACK>
-__device__ __forceinline__ unsigned trace_ray(const SceneDev &sc, RayRegs &r, STACK &st, Counters &cnt)
+__device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK &st, Counters &cnt,
+                                         unsigned min_active)
 {
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+    RayRegs &r = s.r;
+    unsigned cur = s.cur;
 
-    const bool negx = (__float_as_uint(r.rd.x) >> 31) != 0;
-    const bool negy = (__float_as_uint(r.rd.y) >> 31) != 0;
-    const bool negz = (__float_as_uint(r.rd.z) >> 31) != 0;
-    const float ordx = r.o.x * r.rd.x, ordy = r.o.y * r.rd.y, ordz = r.o.z * r.rd.z;
-
-    unsigned hit = 0xFFFFFFFFu;
-    unsigned cur = sc.root_ref;
-    st.sp = 0;
-
-    while (true) {
+    while (cur != kDone) {
         // ---- inner nodes
         while (!(cur & kLeafBit)) {
             const float4 bx = nodes[(size_t)cur * 4 + 0];
@@ -222,18 +247,18 @@ __device__ __forceinline__ unsigned trace_ray(const SceneDev &sc, RayRegs &r, ST
             const float4 lk = nodes[(size_t)cur * 4 + 3];
             if (STATS) cnt.inner++;
             // near/far plane per child, picked by the sign bit of 1/d
-            const float nxl = negx ? bx.z : bx.x, nxr = negx ? bx.w : bx.y;
-            const float fxl = negx ? bx.x : bx.z, fxr = negx ? bx.y : bx.w;
-            const float nyl = negy ? by.z : by.x, nyr = negy ? by.w : by.y;
-            const float fyl = negy ? by.x : by.z, fyr = negy ? by.y : by.w;
-            const float nzl = negz ? bz.z : bz.x, nzr = negz ? bz.w : bz.y;
-            const float fzl = negz ? bz.x : bz.z, fzr = negz ? bz.y : bz.w;
-            const float tnxl = __fmaf_rn(nxl, r.rd.x, -ordx), tnxr = __fmaf_rn(nxr, r.rd.x, -ordx);
-            const float tfxl = __fmaf_rn(fxl, r.rd.x, -ordx), tfxr = __fmaf_rn(fxr, r.rd.x, -ordx);
-            const float tnyl = __fmaf_rn(nyl, r.rd.y, -ordy), tnyr = __fmaf_rn(nyr, r.rd.y, -ordy);
-            const float tfyl = __fmaf_rn(fyl, r.rd.y, -ordy), tfyr = __fmaf_rn(fyr, r.rd.y, -ordy);
-            const float tnzl = __fmaf_rn(nzl, r.rd.z, -ordz), tnzr = __fmaf_rn(nzr, r.rd.z, -ordz);
-            const float tfzl = __fmaf_rn(fzl, r.rd.z, -ordz), tfzr = __fmaf_rn(fzr, r.rd.z, -ordz);
+            const float nxl = s.negx ? bx.z : bx.x, nxr = s.negx ? bx.w : bx.y;
+            const float fxl = s.negx ? bx.x : bx.z, fxr = s.negx ? bx.y : bx.w;
+            const float nyl = s.negy ? by.z : by.x, nyr = s.negy ? by.w : by.y;
+            const float fyl = s.negy ? by.x : by.z, fyr = s.negy ? by.y : by.w;
+            const float nzl = s.negz ? bz.z : bz.x, nzr = s.negz ? bz.w : bz.y;
+            const float fzl = s.negz ? bz.x : bz.z, fzr = s.negz ? bz.y : bz.w;
+            const float tnxl = __fmaf_rn(nxl, r.rd.x, -s.ordx), tnxr = __fmaf_rn(nxr, r.rd.x, -s.ordx);
+            const float tfxl = __fmaf_rn(fxl, r.rd.x, -s.ordx), tfxr = __fmaf_rn(fxr, r.rd.x, -s.ordx);
+            const float tnyl = __fmaf_rn(nyl, r.rd.y, -s.ordy), tnyr = __fmaf_rn(nyr, r.rd.y, -s.ordy);
+            const float tfyl = __fmaf_rn(fyl, r.rd.y, -s.ordy), tfyr = __fmaf_rn(fyr, r.rd.y, -s.ordy);
+            const float tnzl = __fmaf_rn(nzl, r.rd.z, -s.ordz), tnzr = __fmaf_rn(nzr, r.rd.z, -s.ordz);
+            const float tfzl = __fmaf_rn(fzl, r.rd.z, -s.ordz), tfzr = __fmaf_rn(fzr, r.rd.z, -s.ordz);
             const float nearl = fmaxf(fmaxf(fmaxf(tnxl, tnyl), tnzl), r.near_t);
             const float nearr = fmaxf(fmaxf(fmaxf(tnxr, tnyr), tnzr), r.near_t);
             const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), r.far_t);
@@ -255,44 +280,149 @@ __device__ __forceinline__ unsigned trace_ray(const SceneDev &sc, RayRegs &r, ST
                 cur = st.sp ? st.pop() : kDone;
             }
         }
-        if (cur == kDone) break;
 
         // ---- leaf
-        unsigned first, count;
-        if (cur & kBigLeafBit) {
-            const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
-            first = bl.first;
-            count = bl.count;
-        } else {
-            first = (cur >> 3) & (kMaxPackedFirst - 1u);
-            count = (cur & 7u) + 1u;
-        }
-        if (STATS) {
-            cnt.leaf++;
-            cnt.tris += count;
-        }
-        bool done = false;
-        for (unsigned i = 0; i < count; i++) {
-            const size_t base = (size_t)(first + i) * 3;
-            const float4 t0 = tris[base + 0];
-            const float4 t1 = tris[base + 1];
-            const float4 t2 = tris[base + 2];
-            const float t = tri_test(t0, t1, t2, r.o, r.d);
-            if (t >= r.near_t && t < r.far_t) {
-                if (ANYHIT) {
-                    hit = 1u;
-                    done = true;
-                    break;
+        if (cur != kDone) {
+            unsigned first, count;
+            if (cur & kBigLeafBit) {
+                const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
+                first = bl.first;
+                count = bl.count;
+            } else {
+                first = (cur >> 3) & (kMaxPackedFirst - 1u);
+                count = (cur & 7u) + 1u;
+            }
+            if (STATS) {
+                cnt.leaf++;
+                cnt.tris += count;
+            }
+            bool occluded = false;
+            for (unsigned i = 0; i < count; i++) {
+                const size_t base = (size_t)(first + i) * 3;
+                const float4 t0 = tris[base + 0];
+                const float4 t1 = tris[base + 1];
+                const float4 t2 = tris[base + 2];
+                const float t = tri_test(t0, t1, t2, r.o, r.d);
+                if (t >= r.near_t && t < r.far_t) {
+                    if (ANYHIT) {
+                        occluded = true;
+                        break;
+                    }
+                    r.far_t = t;
+                    s.hit = __float_as_uint(t2.y);
                 }
-                r.far_t = t;
-                hit = __float_as_uint(t2.y);
+            }
+            if (ANYHIT && occluded) {
+                s.hit = 1u;
+                cur = kDone;
+            } else {
+                cur = st.sp ? st.pop() : kDone;
             }
         }
-        if (done) break;
-        cur = st.sp ? st.pop() : kDone;
-        if (cur == kDone) break;
+
+        // ---- too few lanes still traversing: let the wave refill
+        if ((unsigned)__popcll(__ballot(true)) < min_active) break;
     }
-    return hit;
+    s.cur = cur;
+}
+
+// Stepwise form of the same traversal: every loop iteration a lane handles ONE
+// item -- an inner node (both child boxes) or one triangle of its current leaf
+// -- and all lanes issue their loads together, whichever kind they are at.
+// Lanes at nodes never wait for lanes inside leaves and vice versa, which is
+// what starves the while-while form on incoherent rays (a third of the lanes
+// active on San-Miguel-class bounce rays).  The per-ray order of node visits
+// and triangle tests is unchanged, so results and counters are identical.
+template <bool ANYHIT, bool STATS, class STACK>
+__device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s, STACK &st, Counters &cnt,
+                                               unsigned min_active)
+{
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+    RayRegs &r = s.r;
+    unsigned cur = s.cur, tri = s.tri, tri_end = s.tri_end;
+
+    while (cur != kDone) {
+        // entering a leaf (from a node step, a pop, or a leaf root)
+        if ((cur & kLeafBit) && tri >= tri_end) {
+            unsigned first, count;
+            if (cur & kBigLeafBit) {
+                const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
+                first = bl.first;
+                count = bl.count;
+            } else {
+                first = (cur >> 3) & (kMaxPackedFirst - 1u);
+                count = (cur & 7u) + 1u;
+            }
+            tri = first;
+            tri_end = first + count;
+            if (STATS) {
+                cnt.leaf++;
+                cnt.tris += count;
+            }
+        }
+        const bool in_leaf = tri < tri_end;
+        const float4 *p = in_leaf ? tris + (size_t)tri * 3 : nodes + (size_t)cur * 4;
+        const float4 a0 = p[0];
+        const float4 a1 = p[1];
+        const float4 a2 = p[2];
+        bool need_pop = false;
+        if (!in_leaf) {
+            const float4 lk = p[3];
+            if (STATS) cnt.inner++;
+            const float nxl = s.negx ? a0.z : a0.x, nxr = s.negx ? a0.w : a0.y;
+            const float fxl = s.negx ? a0.x : a0.z, fxr = s.negx ? a0.y : a0.w;
+            const float nyl = s.negy ? a1.z : a1.x, nyr = s.negy ? a1.w : a1.y;
+            const float fyl = s.negy ? a1.x : a1.z, fyr = s.negy ? a1.y : a1.w;
+            const float nzl = s.negz ? a2.z : a2.x, nzr = s.negz ? a2.w : a2.y;
+            const float fzl = s.negz ? a2.x : a2.z, fzr = s.negz ? a2.y : a2.w;
+            const float tnxl = __fmaf_rn(nxl, r.rd.x, -s.ordx), tnxr = __fmaf_rn(nxr, r.rd.x, -s.ordx);
+            const float tfxl = __fmaf_rn(fxl, r.rd.x, -s.ordx), tfxr = __fmaf_rn(fxr, r.rd.x, -s.ordx);
+            const float tnyl = __fmaf_rn(nyl, r.rd.y, -s.ordy), tnyr = __fmaf_rn(nyr, r.rd.y, -s.ordy);
+            const float tfyl = __fmaf_rn(fyl, r.rd.y, -s.ordy), tfyr = __fmaf_rn(fyr, r.rd.y, -s.ordy);
+            const float tnzl = __fmaf_rn(nzl, r.rd.z, -s.ordz), tnzr = __fmaf_rn(nzr, r.rd.z, -s.ordz);
+            const float tfzl = __fmaf_rn(fzl, r.rd.z, -s.ordz), tfzr = __fmaf_rn(fzr, r.rd.z, -s.ordz);
+            const float nearl = fmaxf(fmaxf(fmaxf(tnxl, tnyl), tnzl), r.near_t);
+            const float nearr = fmaxf(fmaxf(fmaxf(tnxr, tnyr), tnzr), r.near_t);
+            const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), r.far_t);
+            const float farr = fminf(fminf(fminf(tfxr, tfyr), tfzr), r.far_t);
+            const bool hl = nearl <= farl;
+            const bool hr = nearr <= farr;
+            const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
+            const bool left_first = ANYHIT ? true : (nearl <= nearr);
+            const unsigned first = left_first ? left : right;
+            const unsigned second = left_first ? right : left;
+            const bool hf = left_first ? hl : hr;
+            const bool hs = left_first ? hr : hl;
+            if (hf) {
+                cur = first;
+                if (hs) st.push(second);
+            } else if (hs) {
+                cur = second;
+            } else {
+                need_pop = true;
+            }
+        } else {
+            const float t = tri_test(a0, a1, a2, r.o, r.d);
+            tri++;
+            if (t >= r.near_t && t < r.far_t) {
+                if (ANYHIT) {
+                    s.hit = 1u;
+                    cur = kDone;
+                    tri = tri_end;
+                } else {
+                    r.far_t = t;
+                    s.hit = __float_as_uint(a2.y);
+                }
+            }
+            need_pop = (tri >= tri_end) && (cur != kDone);
+        }
+        if (need_pop) cur = st.sp ? st.pop() : kDone;
+        if ((unsigned)__popcll(__ballot(true)) < min_active) break;
+    }
+    s.cur = cur;
+    s.tri = tri;
+    s.tri_end = tri_end;
 }
 
 template <bool STATS>
@@ -313,23 +443,26 @@ constexpr int kBlock = RTC_TRACE_BLOCK;
 constexpr int kLdsDepth = RTC_LDS_STACK_DEPTH;
 
 // ------------------------------------------------------------------------
-// extend / occluded on StreamRay arrays (the drop-in trace boundary)
+// persistent trace kernel
+//
+// The grid is sized to the chip (resident blocks only).  Each wave owns 64
+// lane states and repeatedly (1) fetches rays for its idle lanes with ONE
+// atomic per refill (ballot + popcount + prefix rank), (2) traverses until fewer
+// than `min_active` lanes are busy.  To keep the fetch counter off the critical
+// path the queue is cut into kFetchRanges ranges with one counter each, 128
+// bytes apart; a wave starts on range (wave id mod kFetchRanges) and moves to
+// the next when its range is exhausted, so all ranges drain together and the
+// tail is at most one ray per lane.
 
-template <bool ANYHIT, bool STATS>
-__global__ __launch_bounds__(kBlock) void trace_stream_kernel(SceneDev sc, rt_stream_ray_dev *rays,
-                                                             unsigned *hits, unsigned char *occluded,
-                                                             unsigned n, unsigned *ovf, StatsDev *stats)
-{
-    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
-    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
-    const unsigned nthreads = gridDim.x * kBlock;
-    Stack<kBlock, kLdsDepth> st;
-    st.lds = lds_stack + threadIdx.x;
-    st.ovf = ovf + gtid;
-    st.ovf_stride = nthreads;
-    Counters cnt{0, 0, 0};
-    unsigned long long nrays = 0;
-    for (unsigned i = gtid; i < n; i += nthreads) {
+
+// IO policies: how rays are read and results written.
+
+struct StreamIO { // rt_stream_ray arrays, the reference's StreamRay boundary
+    rt_stream_ray_dev *rays;
+    unsigned *hits;
+    unsigned char *occluded;
+    __device__ __forceinline__ RayRegs load(unsigned i) const
+    {
         const float4 of = rays[i].origin_far;
         const float4 rn = rays[i].dir_recip_near;
         const float4 dd = rays[i].direction;
@@ -339,38 +472,28 @@ __global__ __launch_bounds__(kBlock) void trace_stream_kernel(SceneDev sc, rt_st
         r.rd = v3(rn.x, rn.y, rn.z);
         r.near_t = rn.w;
         r.d = v3(dd.x, dd.y, dd.z);
-        const unsigned h = trace_ray<ANYHIT, STATS>(sc, r, st, cnt);
-        nrays++;
+        return r;
+    }
+    template <bool ANYHIT>
+    __device__ __forceinline__ void store(const LaneState &s) const
+    {
         if (ANYHIT) {
-            occluded[i] = (unsigned char)(h == 1u);
+            occluded[s.index] = (unsigned char)(s.hit == 1u);
         } else {
-            hits[i] = h;
-            rays[i].origin_far.w = r.far_t;
+            hits[s.index] = s.hit;
+            rays[s.index].origin_far.w = s.r.far_t;
         }
     }
-    flush_stats<STATS>(cnt, nrays, stats);
-}
+};
 
-// ------------------------------------------------------------------------
-// extend / connect on the render pipeline's queues
-
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void extend_kernel(SceneDev sc, QRay *rays, unsigned *hit_ids,
-                                                       const unsigned *n_ptr, unsigned *ovf,
-                                                       StatsDev *stats)
-{
-    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
-    const unsigned n = *n_ptr;
-    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
-    const unsigned nthreads = gridDim.x * kBlock;
-    Stack<kBlock, kLdsDepth> st;
-    st.lds = lds_stack + threadIdx.x;
-    st.ovf = ovf + gtid;
-    st.ovf_stride = nthreads;
-    Counters cnt{0, 0, 0};
-    unsigned long long nrays = 0;
-    const float4 *rq = reinterpret_cast<const float4 *>(rays);
-    for (unsigned i = gtid; i < n; i += nthreads) {
+struct QueueIO { // render pipeline queues
+    QRay *rays;
+    unsigned *hit_ids;         // extend
+    const ShadowInfo *infos;   // connect
+    float *rad_r, *rad_g, *rad_b;
+    __device__ __forceinline__ RayRegs load(unsigned i) const
+    {
+        const float4 *rq = reinterpret_cast<const float4 *>(rays);
         const float4 a = rq[(size_t)i * 2 + 0];
         const float4 b = rq[(size_t)i * 2 + 1];
         RayRegs r;
@@ -379,56 +502,99 @@ __global__ __launch_bounds__(kBlock) void extend_kernel(SceneDev sc, QRay *rays,
         r.d = v3(b.x, b.y, b.z);
         r.far_t = b.w;
         r.rd = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z); // src/ray.rs:18
-        const unsigned h = trace_ray<false, STATS>(sc, r, st, cnt);
-        nrays++;
-        hit_ids[i] = h;
-        rays[i].far_t = r.far_t;
+        return r;
     }
-    flush_stats<STATS>(cnt, nrays, stats);
-}
-
-// Any-hit for the shadow queue; an un-occluded ray adds its weight to the
-// radiance slot of its path (src/integrators/integrate_stream.rs:152-161).
-// A path has at most one shadow ray per bounce and launches are stream
-// ordered, so the read-modify-write needs no atomic.
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void connect_kernel(SceneDev sc, const QRay *rays,
-                                                        const ShadowInfo *infos, const unsigned *n_ptr,
-                                                        float *rad_r, float *rad_g, float *rad_b,
-                                                        unsigned *ovf, StatsDev *stats)
-{
-    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
-    const unsigned n = *n_ptr;
-    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
-    const unsigned nthreads = gridDim.x * kBlock;
-    Stack<kBlock, kLdsDepth> st;
-    st.lds = lds_stack + threadIdx.x;
-    st.ovf = ovf + gtid;
-    st.ovf_stride = nthreads;
-    Counters cnt{0, 0, 0};
-    unsigned long long nrays = 0;
-    const float4 *rq = reinterpret_cast<const float4 *>(rays);
-    const float4 *iq = reinterpret_cast<const float4 *>(infos);
-    for (unsigned i = gtid; i < n; i += nthreads) {
-        const float4 a = rq[(size_t)i * 2 + 0];
-        const float4 b = rq[(size_t)i * 2 + 1];
-        RayRegs r;
-        r.o = v3(a.x, a.y, a.z);
-        r.near_t = a.w;
-        r.d = v3(b.x, b.y, b.z);
-        r.far_t = b.w;
-        r.rd = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
-        const unsigned h = trace_ray<true, STATS>(sc, r, st, cnt);
-        nrays++;
-        if (h != 1u) {
-            const float4 w = iq[i];
-            const unsigned slot = __float_as_uint(w.w);
-            rad_r[slot] += w.x;
-            rad_g[slot] += w.y;
-            rad_b[slot] += w.z;
+    template <bool ANYHIT>
+    __device__ __forceinline__ void store(const LaneState &s) const
+    {
+        if (ANYHIT) {
+            // an un-occluded shadow ray adds its weight to the radiance slot of its
+            // path (src/integrators/integrate_stream.rs:152-161).  A path has at
+            // most one shadow ray per bounce and launches are stream ordered, so
+            // the read-modify-write needs no atomic.
+            if (s.hit != 1u) {
+                const float4 w = reinterpret_cast<const float4 *>(infos)[s.index];
+                const unsigned slot = __float_as_uint(w.w);
+                rad_r[slot] += w.x;
+                rad_g[slot] += w.y;
+                rad_b[slot] += w.z;
+            }
+        } else {
+            hit_ids[s.index] = s.hit;
+            rays[s.index].far_t = s.r.far_t;
         }
     }
-    flush_stats<STATS>(cnt, nrays, stats);
+};
+
+template <bool ANYHIT, bool STATS, int MODE, class IO>
+__global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel(SceneDev sc, IO io, const unsigned *n_ptr, unsigned n_val,
+                                                      TraceLaunch tl)
+{
+    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
+    const unsigned n = n_ptr ? *n_ptr : n_val;
+    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
+    Stack<kBlock, kLdsDepth> st;
+    st.lds = lds_stack + threadIdx.x;
+    st.ovf = tl.ovf + gtid;
+    st.ovf_stride = gridDim.x * kBlock;
+    st.sp = 0;
+    Counters cnt{0, 0, 0};
+    unsigned long long nrays = 0;
+
+    const unsigned range_len = (n + kFetchRanges - 1u) / kFetchRanges;
+    unsigned range = (gtid >> 6) % kFetchRanges; // wave-uniform
+    unsigned ranges_left = kFetchRanges;         // ranges not yet seen empty by this wave
+    const unsigned lane = lane_id();
+
+    LaneState s;
+    s.cur = kDone;
+    s.have_ray = false;
+
+    while (true) {
+        // ---- refill idle lanes
+        unsigned long long idle_mask = __ballot(!s.have_ray);
+        while (ranges_left != 0 && idle_mask != 0) {
+            const unsigned need = (unsigned)__popcll(idle_mask);
+            const unsigned rank = prefix_count(idle_mask);
+            const unsigned leader = (unsigned)__ffsll((long long)idle_mask) - 1u;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&tl.fetch[range * kFetchStride], need);
+            base = (unsigned)__shfl((int)base, (int)leader);
+            const unsigned begin = range * range_len;
+            const unsigned end = (begin + range_len < n) ? begin + range_len : n; // begin may exceed n: empty
+            const unsigned idx = begin + base + rank;
+            if (!s.have_ray && begin + base < end && idx < end) {
+                lane_begin(s, sc, io.load(idx), idx);
+                st.sp = 0;
+                if (STATS) nrays++;
+            }
+            if (begin + base + need > end || begin >= end) { // range exhausted by this fetch
+                range = (range + 1u) % kFetchRanges;
+                ranges_left--;
+            }
+            idle_mask = __ballot(!s.have_ray);
+        }
+        if (__ballot(s.have_ray) == 0) break; // nothing in flight and nothing left to fetch
+
+        // ---- traverse
+        if (MODE == 0)
+            traverse<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u);
+        else
+            traverse_steps<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u);
+
+        // ---- retire finished rays
+        if (s.have_ray && s.cur == kDone) {
+            io.template store<ANYHIT>(s);
+            s.have_ray = false;
+        }
+    }
+    flush_stats<STATS>(cnt, nrays, tl.stats);
+}
+
+// add n to total_rays when per-visit statistics are off
+__global__ void count_rays_kernel(const unsigned *n_ptr, StatsDev *stats)
+{
+    atomicAdd(&stats->total_rays, (unsigned long long)*n_ptr);
 }
 
 // ------------------------------------------------------------------------
@@ -798,12 +964,6 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *accum, unsign
     }
 }
 
-// add n to total_rays when per-visit statistics are off
-__global__ void count_rays_kernel(const unsigned *n_ptr, StatsDev *stats)
-{
-    atomicAdd(&stats->total_rays, (unsigned long long)*n_ptr);
-}
-
 // ------------------------------------------------------------------------
 // launchers
 
@@ -814,52 +974,61 @@ static unsigned trace_grid(unsigned n, unsigned max_blocks)
     return need < max_blocks ? need : max_blocks;
 }
 
-void launch_trace_stream(bool anyhit, bool stats, const SceneDev &sc, rt_stream_ray_dev *rays, unsigned *hits,
-                         unsigned char *occluded, unsigned n, unsigned *ovf, StatsDev *dstats,
-                         unsigned max_blocks, hipStream_t stream)
+template <int MODE, class IO>
+static void launch_trace_mode(bool anyhit, bool stats, const SceneDev &sc, const IO &io, const unsigned *n_ptr,
+                              unsigned n_val, unsigned grid, const TraceLaunch &tl, hipStream_t stream)
 {
-    if (n == 0) return;
-    const unsigned grid = trace_grid(n, max_blocks);
     if (anyhit) {
         if (stats)
-            hipLaunchKernelGGL((trace_stream_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
-                               hits, occluded, n, ovf, dstats);
+            hipLaunchKernelGGL((trace_kernel<true, true, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                               n_ptr, n_val, tl);
         else
-            hipLaunchKernelGGL((trace_stream_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
-                               hits, occluded, n, ovf, dstats);
+            hipLaunchKernelGGL((trace_kernel<true, false, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                               n_ptr, n_val, tl);
     } else {
         if (stats)
-            hipLaunchKernelGGL((trace_stream_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
-                               hits, occluded, n, ovf, dstats);
+            hipLaunchKernelGGL((trace_kernel<false, true, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                               n_ptr, n_val, tl);
         else
-            hipLaunchKernelGGL((trace_stream_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays,
-                               hits, occluded, n, ovf, dstats);
+            hipLaunchKernelGGL((trace_kernel<false, false, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                               n_ptr, n_val, tl);
     }
 }
 
-void launch_extend(bool stats, const SceneDev &sc, QRay *rays, unsigned *hit_ids, const unsigned *n_ptr,
-                   unsigned n_upper, unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream)
+template <class IO>
+static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &io, const unsigned *n_ptr,
+                         unsigned n_val, unsigned n_upper, const TraceLaunch &tl, unsigned max_blocks,
+                         hipStream_t stream)
 {
     const unsigned grid = trace_grid(n_upper, max_blocks);
-    if (stats)
-        hipLaunchKernelGGL((extend_kernel<true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, hit_ids, n_ptr,
-                           ovf, dstats);
+    if (tl.mode == 0)
+        launch_trace_mode<0>(anyhit, stats, sc, io, n_ptr, n_val, grid, tl, stream);
     else
-        hipLaunchKernelGGL((extend_kernel<false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, hit_ids, n_ptr,
-                           ovf, dstats);
+        launch_trace_mode<1>(anyhit, stats, sc, io, n_ptr, n_val, grid, tl, stream);
+}
+
+void launch_trace_stream(bool anyhit, bool stats, const SceneDev &sc, rt_stream_ray_dev *rays, unsigned *hits,
+                         unsigned char *occluded, unsigned n, const TraceLaunch &tl, unsigned max_blocks,
+                         hipStream_t stream)
+{
+    if (n == 0) return;
+    StreamIO io{rays, hits, occluded};
+    launch_trace(anyhit, stats, sc, io, nullptr, n, n, tl, max_blocks, stream);
+}
+
+void launch_extend(bool stats, const SceneDev &sc, QRay *rays, unsigned *hit_ids, const unsigned *n_ptr,
+                   unsigned n_upper, const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream)
+{
+    QueueIO io{rays, hit_ids, nullptr, nullptr, nullptr, nullptr};
+    launch_trace(false, stats, sc, io, n_ptr, 0u, n_upper, tl, max_blocks, stream);
 }
 
 void launch_connect(bool stats, const SceneDev &sc, const QRay *rays, const ShadowInfo *infos,
                     const unsigned *n_ptr, unsigned n_upper, float *rad_r, float *rad_g, float *rad_b,
-                    unsigned *ovf, StatsDev *dstats, unsigned max_blocks, hipStream_t stream)
+                    const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream)
 {
-    const unsigned grid = trace_grid(n_upper, max_blocks);
-    if (stats)
-        hipLaunchKernelGGL((connect_kernel<true>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, infos, n_ptr,
-                           rad_r, rad_g, rad_b, ovf, dstats);
-    else
-        hipLaunchKernelGGL((connect_kernel<false>), dim3(grid), dim3(kBlock), 0, stream, sc, rays, infos, n_ptr,
-                           rad_r, rad_g, rad_b, ovf, dstats);
+    QueueIO io{const_cast<QRay *>(rays), nullptr, infos, rad_r, rad_g, rad_b};
+    launch_trace(true, stats, sc, io, n_ptr, 0u, n_upper, tl, max_blocks, stream);
 }
 
 void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream)
@@ -911,18 +1080,13 @@ void launch_resolve(const float *accum, unsigned long long npix, unsigned char *
 
 int trace_blocks_per_cu()
 {
-    int a = 0, b = 0, c = 0, d = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, trace_stream_kernel<false, false>, kBlock, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, trace_stream_kernel<false, true>, kBlock, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, extend_kernel<false>, kBlock, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, connect_kernel<false>, kBlock, 0);
-    int m = a;
-    if (b > m) m = b;
-    if (c > m) m = c;
-    if (d > m) m = d;
-    if (m < 1) m = 1;
-    if (m > 8) m = 8;
-    return m;
+    int best = 1;
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<false, false, 1, QueueIO>, kBlock, 0) == hipSuccess && v > best) best = v;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<true, false, 0, QueueIO>, kBlock, 0) == hipSuccess && v > best) best = v;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<false, true, 1, StreamIO>, kBlock, 0) == hipSuccess && v > best) best = v;
+    if (best > 8) best = 8;
+    return best;
 }
 
 } // namespace rtc

@@ -98,6 +98,9 @@ struct rt_ctx {
     DevBuf ovf;             // traversal stack overflow area
     unsigned ovf_depth = 0; // entries per thread available in ovf
     DevBuf dstats;
+    DevBuf fetch; // ray-fetch counters of the stream entry points
+    unsigned min_active[2] = {48, 48}; // [0] closest-hit, [1] any-hit launches
+    unsigned trav_mode[2] = {1, 1};    // traversal loop form per launch kind (see TraceLaunch::mode)
     Workspace ws;
     uint64_t max_paths = 1ull << 24;
     DevBuf io_a, io_b; // staging for the host-buffer entry points
@@ -183,7 +186,24 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
         delete ctx;
         return fail(RT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
+    if (const char *env = getenv("RTCORE_MIN_ACTIVE")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64) ctx->min_active[0] = ctx->min_active[1] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_TRAVERSAL")) {
+        int v = atoi(env);
+        if (v == 0 || v == 1) ctx->trav_mode[0] = ctx->trav_mode[1] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_MIN_ACTIVE_EXTEND")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64) ctx->min_active[0] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_MIN_ACTIVE_CONNECT")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64) ctx->min_active[1] = (unsigned)v;
+    }
     int rc = ctx->dstats.ensure(2 * sizeof(StatsDev));
+    if (rc == RT_OK) rc = ctx->fetch.ensure(kFetchUints * sizeof(unsigned));
     if (rc == RT_OK) rc = ensure_overflow(ctx, 0);
     if (rc != RT_OK) {
         rt_ctx_destroy(ctx);
@@ -204,6 +224,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     }
     ctx->ovf.release();
     ctx->dstats.release();
+    ctx->fetch.release();
     ctx->io_a.release();
     ctx->io_b.release();
     Workspace &w = ctx->ws;
@@ -239,6 +260,24 @@ extern "C" int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches
         HIP_TRY(hipEventElapsedTime(&v, t.start, t.stop));
         ms[t.kind] += v;
         launches[t.kind] += 1;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_last_launch_ms(rt_ctx *ctx, float *ms, uint32_t *kind, uint32_t cap, uint32_t *count)
+{
+    if (!ctx || !count || (cap && (!ms || !kind)))
+        return fail(RT_ERR_INVALID, "rt_ctx_last_launch_ms: NULL argument");
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    *count = (uint32_t)ctx->used;
+    for (size_t i = 0; i < ctx->used && i < cap; i++) {
+        TimedLaunch &t = ctx->pool[i];
+        HIP_TRY(hipEventSynchronize(t.stop));
+        float v = 0.f;
+        HIP_TRY(hipEventElapsedTime(&v, t.start, t.stop));
+        ms[i] = v;
+        kind[i] = (uint32_t)t.kind;
     }
     return RT_OK;
 }
@@ -473,8 +512,10 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     size_t slot;
     int rc = timed_begin(ctx, anyhit ? 1 : 0, s, &slot);
     if (rc != RT_OK) return rc;
-    launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, (unsigned *)ctx->ovf.p,
-                        (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0), ctx->max_blocks, s);
+    HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
+    TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
+                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_mode[anyhit ? 1 : 0]};
+    launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
     rc = timed_end(ctx, slot, s);
     if (rc != RT_OK) return rc;
@@ -697,8 +738,11 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
     if (slots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rt_render_device: pass of %llu paths exceeds 2^32",
                                            (unsigned long long)slots);
 
-    const uint32_t nb = params->max_bounces + 1;  // extend launches per pass
-    const uint32_t ncounters = 2 * nb + 2;        // ray count per depth (+1), shadow count per depth
+    const uint32_t nb = params->max_bounces + 1; // extend launches per pass
+    // per pass: ray count per depth (nb+1), shadow count per depth (nb), then the
+    // ray-fetch counters of the 2*nb trace launches; zeroed by one memset
+    const uint32_t nqueue = (2 * nb + 2 + 31u) & ~31u;
+    const uint32_t ncounters = nqueue + 2 * nb * kFetchUints;
     rc = ensure_workspace(ctx, slots, ncounters);
     if (rc != RT_OK) return rc;
     Workspace &w = ctx->ws;
@@ -735,6 +779,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             HIP_TRY(hipMemsetAsync(counters, 0, (size_t)ncounters * sizeof(uint32_t), s));
             uint32_t *n_ray = counters;          // [0..nb]
             uint32_t *n_sh = counters + nb + 1;  // [0..nb-1]
+            uint32_t *fetch = counters + nqueue; // [2*nb][kFetchUints]
             int cur = 0;
             size_t slot;
             rc = timed_begin(ctx, 2, s, &slot);
@@ -746,8 +791,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             for (uint32_t b = 0; b < nb; b++) {
                 rc = timed_begin(ctx, 0, s, &slot);
                 if (rc != RT_OK) return rc;
+                TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0], ctx->trav_mode[0]};
                 launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
-                              ps.num_slots, ovf, dstats, ctx->max_blocks, s);
+                              ps.num_slots, tle, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
                 if (want && !visit) launch_count_rays(&n_ray[b], dstats, s);
@@ -776,8 +822,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
 
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
+                TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1], ctx->trav_mode[1]};
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
-                               &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, ovf, dstats + 1, ctx->max_blocks, s);
+                               &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
                 if (want && !visit) launch_count_rays(&n_sh[b], dstats + 1, s);

@@ -1,0 +1,27 @@
+#!/bin/bash
+# PMC passes (one rocprofv3 run per counter set, no tracing flags besides the
+# implicit kernel dispatch records).  WORKLOAD=..., sets are fixed below.
+set -e
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+WL=${WORKLOAD:-sponza-class}
+OUT=gpurun_out/pmc_$WL
+mkdir -p $OUT
+i=0
+while read -r set; do
+  [ -z "$set" ] && continue
+  i=$((i+1))
+  rm -rf $OUT/p$i
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 2 --warmup 0 --workload $WL --no-cpu-baseline ${BENCH_ARGS} > $OUT/p$i.log 2>&1 || { tail -20 $OUT/p$i.log; exit 1; }
+  echo "pass $i ok: $set"
+done <<SETS
+SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_WR
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+FETCH_SIZE
+WRITE_SIZE TCC_EA0_RDREQ_32B_sum
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
+GRBM_GUI_ACTIVE GRBM_COUNT
+SETS
+python3 scripts/pmc_summary.py $OUT > $OUT/summary.txt
+cat $OUT/summary.txt
