@@ -224,11 +224,22 @@ int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches[3]);
  * 2 other.  *count receives the total number of timed launches. */
 int rt_ctx_last_launch_ms(rt_ctx *ctx, float *ms, uint32_t *kind, uint32_t cap, uint32_t *count);
 
+/* Diagnostic: the ordering step the renderer applies to its ray queues, on
+ * host buffers.  perm receives the indices 0..n-1 ordered by bits
+ * [32-bits, 32) of keys (stable).  No reference counterpart: the reference
+ * never reorders rays. */
+int rt_debug_sort_keys(rt_ctx *ctx, const uint32_t *keys, uint32_t n, uint32_t bits, uint32_t *perm);
+
 /* Counters of the most recent trace or render call that asked for statistics,
  * split by traversal kind: out[0] closest-hit (extend) launches, out[1]
  * any-hit (connect) launches.  Their sum is what that call added to its
  * rt_trace_stats argument (src/trace_stats.rs keeps one total only). */
 int rt_ctx_last_stats_split(rt_ctx *ctx, rt_trace_stats out[2]);
+
+/* Longest single ray (node visits + triangle tests) of the most recent call
+ * that collected per-visit statistics: out[0] closest-hit, out[1] any-hit.  A
+ * kernel cannot end before its longest ray does; this is the tail diagnostic. */
+int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

@@ -95,7 +95,9 @@ EXPORTS = {
     "rt_ctx_destroy": (None, [_vp]),
     "rt_ctx_set_max_paths": (C.c_int, [_vp, C.c_uint64]),
     "rt_ctx_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint32 * 3)]),
+    "rt_debug_sort_keys": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "rt_ctx_last_launch_ms": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rt_ctx_last_max_ray_steps": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
     "rt_ctx_last_stats_split": (C.c_int, [_vp, C.POINTER(TraceStats * 2)]),
     "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
@@ -206,6 +208,13 @@ class Context:
         names = ("extend", "connect", "other")
         return {n: float(ms[i]) for i, n in enumerate(names)}, {n: int(ln[i]) for i, n in enumerate(names)}
 
+    def debug_sort_keys(self, keys, bits=32):
+        """Indices 0..n-1 ordered (stably) by the top `bits` bits of u32 keys."""
+        k = np.ascontiguousarray(keys, dtype=np.uint32)
+        perm = np.zeros(k.shape[0], dtype=np.uint32)
+        _check(_lib.rt_debug_sort_keys(self.h, _p(k), k.shape[0], int(bits), _p(perm)))
+        return perm
+
     def last_launch_ms(self, cap=4096):
         """[(kind, ms)] of the last call's timed launches in issue order; kind is
         'extend', 'connect' or 'other'."""
@@ -215,6 +224,11 @@ class Context:
         _check(_lib.rt_ctx_last_launch_ms(self.h, _p(ms), _p(kind), cap, C.byref(n)))
         names = ("extend", "connect", "other")
         return [(names[int(kind[i])], float(ms[i])) for i in range(min(cap, n.value))]
+
+    def last_max_ray_steps(self):
+        out = (C.c_uint64 * 2)()
+        _check(_lib.rt_ctx_last_max_ray_steps(self.h, C.byref(out)))
+        return int(out[0]), int(out[1])
 
     def last_stats_split(self):
         """Counters of the last call with statistics: (closest-hit, any-hit)."""

@@ -92,6 +92,7 @@ struct StatsDev {
     unsigned long long inner_rays;
     unsigned long long leaf_rays;
     unsigned long long obj_intersect;
+    unsigned long long max_ray_steps; // most node visits + triangle tests any single ray needed
 };
 
 } // namespace rtc

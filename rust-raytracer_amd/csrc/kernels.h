@@ -16,7 +16,7 @@
 // occupancy the trace kernels are compiled for (waves per SIMD): bounds the
 // VGPR allocation; together with the LDS stack it sets resident blocks per CU
 #ifndef RTC_TRACE_WAVES_PER_SIMD
-#define RTC_TRACE_WAVES_PER_SIMD 6
+#define RTC_TRACE_WAVES_PER_SIMD 5
 #endif
 
 namespace rtc {
@@ -33,6 +33,12 @@ struct TraceLaunch {
     StatsDev *stats;
     unsigned min_active; // a wave refills when fewer lanes than this are traversing (1..64)
     unsigned mode;       // 0 = while-while loop, 1 = one item (node or triangle) per iteration
+    const unsigned *perm; // optional: process ray perm[i] at position i (queue sorted by key), or null
+    // stragglers: a ray that has used coop_steps loop iterations is finished by its
+    // whole wave on a wave-private work stack of coop_cap 8-byte entries (coop + wave*cap)
+    void *coop;
+    unsigned coop_cap;
+    unsigned coop_steps; // 0xFFFFFFFF = never
 };
 
 // StreamRay (src/ray.rs:6-12) as three float4.
@@ -83,7 +89,20 @@ struct ShadeArgs {
     float light_intensity[3];
     uint32_t max_bounces;
     uint32_t seed_key;
+    // optional sort keys (Morton code of the ray origin), null = not wanted
+    uint32_t *shadow_keys;
+    uint32_t *bounce_keys;
+    float key_lo[3];
+    float key_scale[3]; // 1024 / extent per axis
+    uint32_t key_mask;  // high bits of the 30-bit code that take part in the order
 };
+
+// sorts (key, index) pairs by bits [begin_bit, end_bit) of the key; indices are
+// 0..n-1.  temp must hold sort_temp_bytes(n) bytes.
+size_t sort_temp_bytes(unsigned n, unsigned begin_bit, unsigned end_bit); // 0 on error, else >= 256
+hipError_t sort_indices_by_key(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out,
+                               unsigned *perm_out, unsigned n, unsigned begin_bit, unsigned end_bit,
+                               hipStream_t stream);
 
 void launch_trace_stream(bool anyhit, bool stats, const SceneDev &sc, rt_stream_ray_dev *rays, unsigned *hits,
                          unsigned char *occluded, unsigned n, const TraceLaunch &tl, unsigned max_blocks,

@@ -136,6 +136,8 @@ struct RayRegs {
 
 struct Counters {
     unsigned inner, leaf, tris;
+    unsigned ray_start; // inner + tris when the lane's current ray began
+    unsigned max_steps; // longest ray this lane has finished
 };
 
 // Per-lane traversal stack: the first kLdsDepth entries live in LDS in
@@ -207,6 +209,7 @@ struct LaneState {
     unsigned tri, tri_end;  // triangle cursor inside the current leaf (stepwise traversal)
     unsigned hit;           // closest: mesh triangle id or ~0u; any-hit: 1 when occluded
     unsigned index;         // position of the ray in its queue
+    unsigned steps;         // loop iterations spent on this ray (straggler detection)
     bool have_ray;
 };
 
@@ -223,6 +226,7 @@ __device__ __forceinline__ void lane_begin(LaneState &s, const SceneDev &sc, con
     s.tri = s.tri_end = 0;
     s.hit = 0xFFFFFFFFu;
     s.index = index;
+    s.steps = 0;
     s.have_ray = true;
 }
 
@@ -231,16 +235,20 @@ __device__ __forceinline__ void lane_begin(LaneState &s, const SceneDev &sc, con
 // to fetch rays for its idle lanes).
 template <bool ANYHIT, bool STATS, class STACK>
 __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK &st, Counters &cnt,
-                                         unsigned min_active)
+                                         unsigned min_active, unsigned max_steps)
 {
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
     RayRegs &r = s.r;
     unsigned cur = s.cur;
+    unsigned steps = s.steps;
 
-    while (cur != kDone) {
+    // a ray that has used max_steps iterations stops here at a node boundary and
+    // is finished by the whole wave (coop_finish)
+    while (cur != kDone && steps < max_steps) {
         // ---- inner nodes
-        while (!(cur & kLeafBit)) {
+        while (!(cur & kLeafBit) && steps < max_steps) {
+            steps++;
             const float4 bx = nodes[(size_t)cur * 4 + 0];
             const float4 by = nodes[(size_t)cur * 4 + 1];
             const float4 bz = nodes[(size_t)cur * 4 + 2];
@@ -282,7 +290,8 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
         }
 
         // ---- leaf
-        if (cur != kDone) {
+        if ((cur & kLeafBit) && cur != kDone) {
+            steps++;
             unsigned first, count;
             if (cur & kBigLeafBit) {
                 const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
@@ -324,6 +333,7 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
         if ((unsigned)__popcll(__ballot(true)) < min_active) break;
     }
     s.cur = cur;
+    s.steps = steps;
 }
 
 // Stepwise form of the same traversal: every loop iteration a lane handles ONE
@@ -335,14 +345,17 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
 // and triangle tests is unchanged, so results and counters are identical.
 template <bool ANYHIT, bool STATS, class STACK>
 __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s, STACK &st, Counters &cnt,
-                                               unsigned min_active)
+                                               unsigned min_active, unsigned max_steps)
 {
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
     RayRegs &r = s.r;
     unsigned cur = s.cur, tri = s.tri, tri_end = s.tri_end;
+    unsigned steps = s.steps;
 
-    while (cur != kDone) {
+    // stop at a node boundary (never inside a leaf) once the ray has used max_steps
+    while (cur != kDone && (steps < max_steps || tri < tri_end)) {
+        steps++;
         // entering a leaf (from a node step, a pop, or a leaf root)
         if ((cur & kLeafBit) && tri >= tri_end) {
             unsigned first, count;
@@ -423,6 +436,201 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
     s.cur = cur;
     s.tri = tri;
     s.tri_end = tri_end;
+    s.steps = steps;
+}
+
+// Cooperative finish of ONE ray by the whole wave.
+//
+// A few rays need 10^4..10^5 traversal steps (grazing rays through dense
+// foliage); one lane walking them at one dependent memory access per step takes
+// tens of milliseconds and becomes the tail of the launch.  Such a ray (lane
+// `p`, parked at a node boundary with `steps >= max_steps`) is finished here
+// with 64 lanes: the pending work -- the lane's current node and its stack -- is
+// moved to a wave-private stack in global memory, and every iteration up to 64
+// entries are popped and processed in parallel (an inner node tests both
+// children and pushes the hit ones with their entry distance; a leaf tests its
+// triangles), with the closest distance reduced across the wave after every
+// iteration and entries beyond it discarded at pop time.
+//
+// The closest distance found is exactly the single-lane result (the same
+// triangle arithmetic on a superset of candidates); on an exact-distance tie
+// the id may be another triangle of the tie, and visit counters of such a ray
+// differ (other visit order, pop-time culling).
+struct CoopItem {
+    unsigned ref;
+    float tnear;
+};
+
+template <bool ANYHIT, bool STATS, int BLOCK, int LDS_DEPTH>
+__device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, Stack<BLOCK, LDS_DEPTH> &st, Counters &cnt,
+                                         unsigned p, CoopItem *work, unsigned cap)
+{
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+    const unsigned lane = lane_id();
+
+    // the ray of lane p, in every lane
+    const V3 o = v3(__shfl(s.r.o.x, p), __shfl(s.r.o.y, p), __shfl(s.r.o.z, p));
+    const V3 d = v3(__shfl(s.r.d.x, p), __shfl(s.r.d.y, p), __shfl(s.r.d.z, p));
+    const V3 rd = v3(__shfl(s.r.rd.x, p), __shfl(s.r.rd.y, p), __shfl(s.r.rd.z, p));
+    const float near_t = __shfl(s.r.near_t, p);
+    float far_t = __shfl(s.r.far_t, p);
+    unsigned hit = (unsigned)__shfl((int)s.hit, p);
+    const float ordx = __shfl(s.ordx, p), ordy = __shfl(s.ordy, p), ordz = __shfl(s.ordz, p);
+    const bool negx = (__float_as_uint(rd.x) >> 31) != 0;
+    const bool negy = (__float_as_uint(rd.y) >> 31) != 0;
+    const bool negz = (__float_as_uint(rd.z) >> 31) != 0;
+
+    // seed: lane p's stack entries (lane e reads entry e) and its current node
+    const int sp_p = __shfl(st.sp, p);
+    const unsigned cur_p = (unsigned)__shfl((int)s.cur, p);
+    unsigned count = 0; // wave-uniform
+    {
+        unsigned *lds_p = st.lds - (threadIdx.x & 63) + p;            // column of lane p
+        unsigned *ovf_p = st.ovf - (size_t)(threadIdx.x & 63) + p;
+        for (int e = (int)lane; e < sp_p; e += 64) {
+            unsigned ref;
+            if (e < LDS_DEPTH)
+                ref = lds_p[e * BLOCK];
+            else
+                ref = ovf_p[(size_t)(e - LDS_DEPTH) * st.ovf_stride];
+            work[e] = CoopItem{ref, -__builtin_inff()};
+        }
+        count = (unsigned)sp_p;
+        if (lane == 0) work[count] = CoopItem{cur_p, -__builtin_inff()};
+        count += 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // Stack bound.  Popping m entries pushes at most 2m, so a batch is sized to keep
+    // count <= lim = cap - reserve; at the limit one entry is popped per iteration,
+    // which is a plain depth-first walk and grows the stack by at most the tree depth
+    // (reserve = max_depth + 2).  The host guarantees cap > reserve + 64 + max_depth.
+    const unsigned lim = cap - (sc.max_depth + 2u);
+    bool found = false; // any-hit result (wave-uniform)
+    while (count != 0 && !(ANYHIT && found)) {
+        unsigned m = count < 64u ? count : 64u;
+        if (count + m > lim) m = lim > count ? lim - count : 1u;
+        CoopItem it{kDone, 0.f};
+        if (lane < m) it = work[count - 1u - lane];
+        count -= m;
+        bool active = lane < m && it.tnear <= far_t;
+
+        // results of this lane for this iteration
+        float best_t = __builtin_inff();
+        unsigned best_id = 0xFFFFFFFFu;
+        bool push_a = false, push_b = false; // a: pushed first (deeper in the stack), b: on top
+        CoopItem ca{kDone, 0.f}, cb{kDone, 0.f};
+
+        if (active && !(it.ref & kLeafBit)) {
+            const float4 bx = nodes[(size_t)it.ref * 4 + 0];
+            const float4 by = nodes[(size_t)it.ref * 4 + 1];
+            const float4 bz = nodes[(size_t)it.ref * 4 + 2];
+            const float4 lk = nodes[(size_t)it.ref * 4 + 3];
+            if (STATS) cnt.inner++;
+            const float nxl = negx ? bx.z : bx.x, nxr = negx ? bx.w : bx.y;
+            const float fxl = negx ? bx.x : bx.z, fxr = negx ? bx.y : bx.w;
+            const float nyl = negy ? by.z : by.x, nyr = negy ? by.w : by.y;
+            const float fyl = negy ? by.x : by.z, fyr = negy ? by.y : by.w;
+            const float nzl = negz ? bz.z : bz.x, nzr = negz ? bz.w : bz.y;
+            const float fzl = negz ? bz.x : bz.z, fzr = negz ? bz.y : bz.w;
+            const float tnxl = __fmaf_rn(nxl, rd.x, -ordx), tnxr = __fmaf_rn(nxr, rd.x, -ordx);
+            const float tfxl = __fmaf_rn(fxl, rd.x, -ordx), tfxr = __fmaf_rn(fxr, rd.x, -ordx);
+            const float tnyl = __fmaf_rn(nyl, rd.y, -ordy), tnyr = __fmaf_rn(nyr, rd.y, -ordy);
+            const float tfyl = __fmaf_rn(fyl, rd.y, -ordy), tfyr = __fmaf_rn(fyr, rd.y, -ordy);
+            const float tnzl = __fmaf_rn(nzl, rd.z, -ordz), tnzr = __fmaf_rn(nzr, rd.z, -ordz);
+            const float tfzl = __fmaf_rn(fzl, rd.z, -ordz), tfzr = __fmaf_rn(fzr, rd.z, -ordz);
+            const float nearl = fmaxf(fmaxf(fmaxf(tnxl, tnyl), tnzl), near_t);
+            const float nearr = fmaxf(fmaxf(fmaxf(tnxr, tnyr), tnzr), near_t);
+            const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), far_t);
+            const float farr = fminf(fminf(fminf(tfxr, tfyr), tfzr), far_t);
+            const bool hl = nearl <= farl;
+            const bool hr = nearr <= farr;
+            const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
+            const bool left_first = nearl <= nearr;
+            // the nearer child goes on top (b), the farther one below (a)
+            const CoopItem cl{left, nearl}, cr{right, nearr};
+            if (hl && hr) {
+                push_a = push_b = true;
+                ca = left_first ? cr : cl;
+                cb = left_first ? cl : cr;
+            } else if (hl || hr) {
+                push_b = true;
+                cb = hl ? cl : cr;
+            }
+        } else if (active) {
+            unsigned first, n;
+            if (it.ref & kBigLeafBit) {
+                const BigLeaf bl = sc.big_leaves[it.ref & 0x3FFFFFFFu];
+                first = bl.first;
+                n = bl.count;
+            } else {
+                first = (it.ref >> 3) & (kMaxPackedFirst - 1u);
+                n = (it.ref & 7u) + 1u;
+            }
+            if (STATS) {
+                cnt.leaf++;
+                cnt.tris += n;
+            }
+            float lane_far = far_t;
+            for (unsigned i = 0; i < n; i++) {
+                const size_t base = (size_t)(first + i) * 3;
+                const float4 t0 = tris[base + 0];
+                const float4 t1 = tris[base + 1];
+                const float4 t2 = tris[base + 2];
+                const float t = tri_test(t0, t1, t2, o, d);
+                if (t >= near_t && t < lane_far) {
+                    lane_far = t;
+                    best_t = t;
+                    best_id = __float_as_uint(t2.y);
+                    if (ANYHIT) break;
+                }
+            }
+        }
+
+        // combine the lanes' hits
+        if (ANYHIT) {
+            found = __ballot(best_t < __builtin_inff()) != 0;
+        } else {
+            float wt = best_t;
+            unsigned wi = best_id;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ot = __shfl_xor(wt, off);
+                const unsigned oi = (unsigned)__shfl_xor((int)wi, off);
+                if (ot < wt || (ot == wt && oi < wi)) {
+                    wt = ot;
+                    wi = oi;
+                }
+            }
+            if (wt < far_t) {
+                far_t = wt;
+                hit = wi;
+            }
+        }
+
+        // push the children: all "a" entries first, then all "b" entries
+        const unsigned long long ma = __ballot(push_a), mb = __ballot(push_b);
+        const unsigned na = (unsigned)__popcll(ma), nb = (unsigned)__popcll(mb);
+        if (push_a) work[count + prefix_count(ma)] = ca;
+        if (push_b) work[count + na + prefix_count(mb)] = cb;
+        count += na + nb;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (lane == p) {
+        if (ANYHIT) {
+            s.hit = found ? 1u : s.hit;
+        } else {
+            s.hit = hit;
+            s.r.far_t = far_t;
+        }
+        s.cur = kDone;
+        s.tri = s.tri_end = 0;
+        st.sp = 0;
+    }
 }
 
 template <bool STATS>
@@ -431,7 +639,13 @@ __device__ __forceinline__ void flush_stats(const Counters &cnt, unsigned long l
     if (!STATS) return;
     unsigned long long a = wave_sum(cnt.inner), b = wave_sum(cnt.leaf), c = wave_sum(cnt.tris),
                        d = wave_sum(rays);
+    unsigned long long m = cnt.max_steps;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(m, off);
+        m = o > m ? o : m;
+    }
     if (lane_id() == 0) {
+        atomicMax(&stats->max_ray_steps, m);
         atomicAdd(&stats->inner_rays, a);
         atomicAdd(&stats->leaf_rays, b);
         atomicAdd(&stats->obj_intersect, c);
@@ -538,7 +752,7 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
     st.ovf = tl.ovf + gtid;
     st.ovf_stride = gridDim.x * kBlock;
     st.sp = 0;
-    Counters cnt{0, 0, 0};
+    Counters cnt{0, 0, 0, 0, 0};
     unsigned long long nrays = 0;
 
     const unsigned range_len = (n + kFetchRanges - 1u) / kFetchRanges;
@@ -564,9 +778,17 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
             const unsigned end = (begin + range_len < n) ? begin + range_len : n; // begin may exceed n: empty
             const unsigned idx = begin + base + rank;
             if (!s.have_ray && begin + base < end && idx < end) {
-                lane_begin(s, sc, io.load(idx), idx);
+                unsigned ray = idx;
+                if (tl.perm) {
+                    ray = tl.perm[idx];
+                    if (ray >= n) ray = idx; // never index outside the queue, whatever the permutation holds
+                }
+                lane_begin(s, sc, io.load(ray), ray);
                 st.sp = 0;
-                if (STATS) nrays++;
+                if (STATS) {
+                    nrays++;
+                    cnt.ray_start = cnt.inner + cnt.tris;
+                }
             }
             if (begin + base + need > end || begin >= end) { // range exhausted by this fetch
                 range = (range + 1u) % kFetchRanges;
@@ -578,14 +800,30 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
 
         // ---- traverse
         if (MODE == 0)
-            traverse<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u);
+            traverse<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else
-            traverse_steps<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u);
+            traverse_steps<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+
+        // ---- stragglers: rays that used up their step budget are finished by the whole wave
+        {
+            unsigned long long parked =
+                __ballot(s.have_ray && s.cur != kDone && s.steps >= tl.coop_steps && s.tri >= s.tri_end);
+            CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
+            while (parked != 0) {
+                const unsigned p = (unsigned)__ffsll((long long)parked) - 1u;
+                coop_finish<ANYHIT, STATS>(sc, s, st, cnt, p, work, tl.coop_cap);
+                parked &= parked - 1ull;
+            }
+        }
 
         // ---- retire finished rays
         if (s.have_ray && s.cur == kDone) {
             io.template store<ANYHIT>(s);
             s.have_ray = false;
+            if (STATS) {
+                const unsigned steps = cnt.inner + cnt.tris - cnt.ray_start;
+                cnt.max_steps = steps > cnt.max_steps ? steps : cnt.max_steps;
+            }
         }
     }
     flush_stats<STATS>(cnt, nrays, tl.stats);
@@ -803,6 +1041,28 @@ __global__ __launch_bounds__(256) void generate_stream_kernel(CameraDev cam, Pas
 // shade: loop body of integrate_tile_stream
 // (src/integrators/integrate_stream.rs:104-138) for every ray of the queue.
 
+// 30-bit Morton code of a point inside the scene bounds (10 bits per axis)
+__device__ __forceinline__ unsigned spread10(unsigned v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ unsigned morton_key(const ShadeArgs &a, const float *p)
+{
+    unsigned q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float f = (p[k] - a.key_lo[k]) * a.key_scale[k];
+        f = fminf(fmaxf(f, 0.f), 1023.f);
+        q[k] = (unsigned)f;
+    }
+    return ((spread10(q[2]) << 2) | (spread10(q[1]) << 1) | spread10(q[0])) & a.key_mask;
+}
+
 struct ShadeOut {
     QRay sh_ray, bn_ray;
     ShadowInfo sh_info;
@@ -904,10 +1164,12 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(ShadeArgs a)
         if (pred[0][it]) {
             a.shadow_rays[pos[0][it]] = out[it].sh_ray;
             a.shadow_infos[pos[0][it]] = out[it].sh_info;
+            if (a.shadow_keys) a.shadow_keys[pos[0][it]] = morton_key(a, out[it].sh_ray.o);
         }
         if (pred[1][it]) {
             a.rays_out[pos[1][it]] = out[it].bn_ray;
             a.infos_out[pos[1][it]] = out[it].bn_info;
+            if (a.bounce_keys) a.bounce_keys[pos[1][it]] = morton_key(a, out[it].bn_ray.o);
         }
     }
 }

@@ -85,6 +85,7 @@ struct TimedLaunch {
 
 struct Workspace {
     DevBuf rays[2], infos[2], hit_ids, shadow_rays, shadow_infos, rad, counters;
+    DevBuf keys[2], keys_sorted, perm[2], sort_temp; // [0] bounce queue, [1] shadow queue
     uint64_t paths = 0;
 };
 
@@ -99,8 +100,15 @@ struct rt_ctx {
     unsigned ovf_depth = 0; // entries per thread available in ovf
     DevBuf dstats;
     DevBuf fetch; // ray-fetch counters of the stream entry points
+    DevBuf coop;  // wave-private work stacks of the cooperative straggler path
+    unsigned coop_cap = 2048;    // entries per wave
+    unsigned coop_steps = 2048;  // a ray is handed to its whole wave after this many loop iterations
     unsigned min_active[2] = {48, 48}; // [0] closest-hit, [1] any-hit launches
     unsigned trav_mode[2] = {1, 1};    // traversal loop form per launch kind (see TraceLaunch::mode)
+    // queues are reordered by the Morton code of the ray origin from these depths
+    // on (depth of the launch that consumes the queue); 0xFFFFFFFF = never
+    unsigned sort_from_depth[2] = {2, 1}; // [0] extend, [1] connect
+    unsigned sort_bits = 21;              // high bits of the 30-bit key that are sorted
     Workspace ws;
     uint64_t max_paths = 1ull << 24;
     DevBuf io_a, io_b; // staging for the host-buffer entry points
@@ -108,6 +116,7 @@ struct rt_ctx {
     size_t used = 0;
     bool timing = true;
     rt_trace_stats last_split[2]{}; // [0] closest-hit launches, [1] any-hit launches of the last call with stats
+    uint64_t last_max_steps[2] = {0, 0};
 };
 
 struct rt_scene {
@@ -117,6 +126,8 @@ struct rt_scene {
     DevBuf nodes, tris, big, normals;
     SceneDev dev{};
     uint64_t device_bytes = 0;
+    float bounds_lo[3] = {0, 0, 0};
+    float key_scale[3] = {0, 0, 0}; // 1024 / extent, for the Morton sort keys
 };
 
 static int ctx_set_device(rt_ctx *ctx) { HIP_TRY(hipSetDevice(ctx->device)); return RT_OK; }
@@ -130,6 +141,15 @@ static int ensure_overflow(rt_ctx *ctx, unsigned max_depth)
     if (rc != RT_OK) return rc;
     ctx->ovf_depth = need;
     return RT_OK;
+}
+
+// cooperative-finish settings of a launch on `sc`: off when the tree is too deep
+// for the fixed work-stack capacity
+static void fill_coop(const rt_ctx *ctx, unsigned max_depth, TraceLaunch &tl)
+{
+    tl.coop = ctx->coop.p;
+    tl.coop_cap = ctx->coop_cap;
+    tl.coop_steps = (2u * max_depth + 68u < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
 }
 
 static int timed_begin(rt_ctx *ctx, int kind, hipStream_t s, size_t *slot)
@@ -194,6 +214,16 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
         int v = atoi(env);
         if (v == 0 || v == 1) ctx->trav_mode[0] = ctx->trav_mode[1] = (unsigned)v;
     }
+    if (const char *env = getenv("RTCORE_SORT_EXTEND_FROM")) ctx->sort_from_depth[0] = (unsigned)atoi(env);
+    if (const char *env = getenv("RTCORE_SORT_CONNECT_FROM")) ctx->sort_from_depth[1] = (unsigned)atoi(env);
+    if (const char *env = getenv("RTCORE_SORT_BITS")) {
+        int v = atoi(env);
+        if (v >= 3 && v <= 30) ctx->sort_bits = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_COOP_STEPS")) {
+        long long v = atoll(env);
+        ctx->coop_steps = (v <= 0 || v >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)v;
+    }
     if (const char *env = getenv("RTCORE_MIN_ACTIVE_EXTEND")) {
         int v = atoi(env);
         if (v >= 1 && v <= 64) ctx->min_active[0] = (unsigned)v;
@@ -204,6 +234,8 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     int rc = ctx->dstats.ensure(2 * sizeof(StatsDev));
     if (rc == RT_OK) rc = ctx->fetch.ensure(kFetchUints * sizeof(unsigned));
+    if (rc == RT_OK)
+        rc = ctx->coop.ensure((size_t)ctx->max_blocks * (RTC_TRACE_BLOCK / 64) * ctx->coop_cap * 8);
     if (rc == RT_OK) rc = ensure_overflow(ctx, 0);
     if (rc != RT_OK) {
         rt_ctx_destroy(ctx);
@@ -225,12 +257,15 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     ctx->ovf.release();
     ctx->dstats.release();
     ctx->fetch.release();
+    ctx->coop.release();
     ctx->io_a.release();
     ctx->io_b.release();
     Workspace &w = ctx->ws;
     w.rays[0].release(); w.rays[1].release(); w.infos[0].release(); w.infos[1].release();
     w.hit_ids.release(); w.shadow_rays.release(); w.shadow_infos.release(); w.rad.release();
     w.counters.release();
+    w.keys[0].release(); w.keys[1].release(); w.keys_sorted.release();
+    w.perm[0].release(); w.perm[1].release(); w.sort_temp.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -264,6 +299,39 @@ extern "C" int rt_ctx_last_kernel_ms(rt_ctx *ctx, float ms[3], uint32_t launches
     return RT_OK;
 }
 
+extern "C" int rt_debug_sort_keys(rt_ctx *ctx, const uint32_t *keys, uint32_t n, uint32_t bits, uint32_t *perm)
+{
+    if (!ctx || (n && (!keys || !perm))) return fail(RT_ERR_INVALID, "rt_debug_sort_keys: NULL argument");
+    if (bits < 1 || bits > 32) return fail(RT_ERR_INVALID, "rt_debug_sort_keys: bits %u outside [1, 32]", bits);
+    if (n == 0) return RT_OK;
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    DevBuf k_in, k_out, p_out, temp;
+    size_t tb = sort_temp_bytes(n, 32u - bits, 32u);
+    if (tb == 0) return fail(RT_ERR_HIP, "radix sort temporary-storage query failed");
+    rc = k_in.ensure((size_t)n * 4);
+    if (rc == RT_OK) rc = k_out.ensure((size_t)n * 4);
+    if (rc == RT_OK) rc = p_out.ensure((size_t)n * 4);
+    if (rc == RT_OK) rc = temp.ensure(tb);
+    hipError_t e = hipSuccess;
+    if (rc == RT_OK) {
+        hipStream_t s = ctx->stream;
+        e = hipMemcpyAsync(k_in.p, keys, (size_t)n * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess)
+            e = sort_indices_by_key(temp.p, temp.bytes, (const unsigned *)k_in.p, (unsigned *)k_out.p,
+                                    (unsigned *)p_out.p, n, 32u - bits, 32u, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(perm, p_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    k_in.release();
+    k_out.release();
+    p_out.release();
+    temp.release();
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_sort_keys: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 extern "C" int rt_ctx_last_launch_ms(rt_ctx *ctx, float *ms, uint32_t *kind, uint32_t cap, uint32_t *count)
 {
     if (!ctx || !count || (cap && (!ms || !kind)))
@@ -287,6 +355,14 @@ extern "C" int rt_ctx_last_stats_split(rt_ctx *ctx, rt_trace_stats out[2])
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_stats_split: NULL argument");
     out[0] = ctx->last_split[0];
     out[1] = ctx->last_split[1];
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2])
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_max_ray_steps: NULL argument");
+    out[0] = ctx->last_max_steps[0];
+    out[1] = ctx->last_max_steps[1];
     return RT_OK;
 }
 
@@ -393,6 +469,20 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     if (rc != RT_OK) {
         rt_scene_destroy(sc);
         return rc;
+    }
+    {
+        float lo[3] = {positions[0], positions[1], positions[2]}, hi[3] = {positions[0], positions[1], positions[2]};
+        for (uint32_t v = 1; v < num_vertices; v++)
+            for (int k = 0; k < 3; k++) {
+                float x = positions[3 * (size_t)v + k];
+                lo[k] = std::min(lo[k], x);
+                hi[k] = std::max(hi[k], x);
+            }
+        for (int k = 0; k < 3; k++) {
+            float ext = hi[k] - lo[k];
+            sc->bounds_lo[k] = lo[k];
+            sc->key_scale[k] = ext > 0.f ? 1024.f / ext : 0.f;
+        }
     }
     sc->dev.nodes = (const DevNode *)sc->nodes.p;
     sc->dev.tris = (const DevTri *)sc->tris.p;
@@ -514,7 +604,8 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
-                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_mode[anyhit ? 1 : 0]};
+                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_mode[anyhit ? 1 : 0], nullptr, nullptr, 0, 0};
+    fill_coop(ctx, sc->dev.max_depth, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
     rc = timed_end(ctx, slot, s);
@@ -525,6 +616,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
         HIP_TRY(hipStreamSynchronize(s));
         for (int k = 0; k < 2; k++) {
             ctx->last_split[k] = rt_trace_stats{};
+            ctx->last_max_steps[k] = h[k].max_ray_steps;
             stats_from_dev(h[k], &ctx->last_split[k]);
             stats_from_dev(h[k], stats);
         }
@@ -680,7 +772,7 @@ int check_params(const rt_render_params *p, const char *who)
 // ------------------------------------------------------------------------
 // render
 
-static int ensure_workspace(rt_ctx *ctx, uint64_t paths, uint32_t ncounters)
+static int ensure_workspace(rt_ctx *ctx, uint64_t paths, uint32_t ncounters, bool sorting, unsigned sort_bits)
 {
     Workspace &w = ctx->ws;
     int rc = RT_OK;
@@ -691,6 +783,16 @@ static int ensure_workspace(rt_ctx *ctx, uint64_t paths, uint32_t ncounters)
     if (rc == RT_OK) rc = w.shadow_infos.ensure(paths * sizeof(ShadowInfo));
     if (rc == RT_OK) rc = w.rad.ensure(paths * 3 * sizeof(float));
     if (rc == RT_OK) rc = w.counters.ensure((size_t)ncounters * sizeof(uint32_t));
+    if (rc == RT_OK && sorting) {
+        for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.keys[i].ensure(paths * sizeof(uint32_t));
+        for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.perm[i].ensure(paths * sizeof(uint32_t));
+        if (rc == RT_OK) rc = w.keys_sorted.ensure(paths * sizeof(uint32_t));
+        if (rc == RT_OK) {
+            size_t tb = sort_temp_bytes((unsigned)paths, 30u - sort_bits, 32u);
+            if (tb == 0) return fail(RT_ERR_HIP, "radix sort temporary-storage query failed");
+            rc = w.sort_temp.ensure(tb);
+        }
+    }
     if (rc == RT_OK) w.paths = std::max(w.paths, paths);
     return rc;
 }
@@ -743,7 +845,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
     // ray-fetch counters of the 2*nb trace launches; zeroed by one memset
     const uint32_t nqueue = (2 * nb + 2 + 31u) & ~31u;
     const uint32_t ncounters = nqueue + 2 * nb * kFetchUints;
-    rc = ensure_workspace(ctx, slots, ncounters);
+    // a queue consumed at depth d is sorted when d >= sort_from_depth
+    const bool sort_any = (nb > ctx->sort_from_depth[0]) || (nb > ctx->sort_from_depth[1]);
+    rc = ensure_workspace(ctx, slots, ncounters, sort_any, ctx->sort_bits);
     if (rc != RT_OK) return rc;
     Workspace &w = ctx->ws;
 
@@ -782,6 +886,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             uint32_t *fetch = counters + nqueue; // [2*nb][kFetchUints]
             int cur = 0;
             size_t slot;
+            const unsigned *perm_extend = nullptr; // order of the ray queue about to be extended
             rc = timed_begin(ctx, 2, s, &slot);
             if (rc != RT_OK) return rc;
             launch_generate(cam, ps, (QRay *)w.rays[cur].p, (PathInfo *)w.infos[cur].p, &n_ray[0], rad_r, rad_g,
@@ -791,7 +896,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             for (uint32_t b = 0; b < nb; b++) {
                 rc = timed_begin(ctx, 0, s, &slot);
                 if (rc != RT_OK) return rc;
-                TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0], ctx->trav_mode[0]};
+                TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0],
+                                ctx->trav_mode[0], perm_extend, nullptr, 0, 0};
+                fill_coop(ctx, sc->dev.max_depth, tle);
                 launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
                               ps.num_slots, tle, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
@@ -814,15 +921,50 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 memcpy(a.light_intensity, light->intensity, sizeof a.light_intensity);
                 a.max_bounces = params->max_bounces;
                 a.seed_key = seed_key;
+                // the shadow queue is consumed at depth b, the bounce queue at depth b+1
+                const bool sort_shadow = b >= ctx->sort_from_depth[1];
+                const bool sort_bounce = (b + 1 < nb) && (b + 1 >= ctx->sort_from_depth[0]);
+                for (int k = 0; k < 3; k++) {
+                    a.key_lo[k] = sc->bounds_lo[k];
+                    a.key_scale[k] = sc->key_scale[k];
+                }
+                a.key_mask = (0x3FFFFFFFu >> (30u - ctx->sort_bits)) << (30u - ctx->sort_bits);
+                a.shadow_keys = sort_shadow ? (uint32_t *)w.keys[1].p : nullptr;
+                a.bounce_keys = sort_bounce ? (uint32_t *)w.keys[0].p : nullptr;
                 rc = timed_begin(ctx, 2, s, &slot);
                 if (rc != RT_OK) return rc;
+                // unused queue tail keeps the largest key so that it sorts behind every ray
+                if (sort_shadow) HIP_TRY(hipMemsetAsync(w.keys[1].p, 0xFF, (size_t)ps.num_slots * sizeof(uint32_t), s));
+                if (sort_bounce) HIP_TRY(hipMemsetAsync(w.keys[0].p, 0xFF, (size_t)ps.num_slots * sizeof(uint32_t), s));
                 launch_shade(a, ps.num_slots, s);
+                const unsigned *perm_connect = nullptr;
+                if (sort_shadow || sort_bounce) {
+                    size_t tb = sort_temp_bytes(ps.num_slots, 30u - ctx->sort_bits, 32u);
+                    if (tb == 0) return fail(RT_ERR_HIP, "radix sort temporary-storage query failed");
+                    rc = w.sort_temp.ensure(tb);
+                    if (rc != RT_OK) return rc;
+                }
+                if (sort_shadow) {
+                    HIP_TRY(sort_indices_by_key(w.sort_temp.p, w.sort_temp.bytes, (const unsigned *)w.keys[1].p,
+                                                (unsigned *)w.keys_sorted.p, (unsigned *)w.perm[1].p, ps.num_slots,
+                                                30u - ctx->sort_bits, 32u, s));
+                    perm_connect = (const unsigned *)w.perm[1].p;
+                }
+                perm_extend = nullptr;
+                if (sort_bounce) {
+                    HIP_TRY(sort_indices_by_key(w.sort_temp.p, w.sort_temp.bytes, (const unsigned *)w.keys[0].p,
+                                                (unsigned *)w.keys_sorted.p, (unsigned *)w.perm[0].p, ps.num_slots,
+                                                30u - ctx->sort_bits, 32u, s));
+                    perm_extend = (const unsigned *)w.perm[0].p;
+                }
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
 
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
-                TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1], ctx->trav_mode[1]};
+                TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1],
+                                ctx->trav_mode[1], perm_connect, nullptr, 0, 0};
+                fill_coop(ctx, sc->dev.max_depth, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
                                &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
@@ -844,6 +986,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
         HIP_TRY(hipStreamSynchronize(s));
         for (int q = 0; q < 2; q++) {
             ctx->last_split[q] = rt_trace_stats{};
+            ctx->last_max_steps[q] = h[q].max_ray_steps;
             if (visit) {
                 stats_from_dev(h[q], &ctx->last_split[q]);
                 stats_from_dev(h[q], stats);
