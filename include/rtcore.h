@@ -146,6 +146,18 @@ const char *rt_version(void);
  * device ordinal. */
 int rt_ctx_create(int device_id, rt_ctx **out);
 void rt_ctx_destroy(rt_ctx *ctx);
+/* Tuning knobs (no reference counterpart).  Names and ranges:
+ *   "coop_steps"        loop iterations after which a ray is finished by its whole
+ *                       wave (0 = never).  Rays handled that way keep their exact
+ *                       hit distance; their visit counters and the id on an
+ *                       exact-distance tie may differ from the single-lane walk.
+ *   "min_active"        1..64, a wave fetches new rays when fewer lanes are busy
+ *   "traversal_depth0", "traversal_deep"   0 = while-while loop, 1 = one item per iteration
+ *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
+ *   "sort_bits"         3..30 key bits that take part in the order
+ *   "timing"            0/1 per-launch HIP events */
+int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value);
+
 /* Upper bound of paths per render pass (workspace is sized from it lazily). */
 int rt_ctx_set_max_paths(rt_ctx *ctx, uint64_t max_paths);
 

@@ -94,6 +94,7 @@ EXPORTS = {
     "rt_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "rt_ctx_destroy": (None, [_vp]),
     "rt_ctx_set_max_paths": (C.c_int, [_vp, C.c_uint64]),
+    "rt_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "rt_ctx_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint32 * 3)]),
     "rt_debug_sort_keys": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "rt_ctx_last_launch_ms": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -196,6 +197,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        _check(_lib.rt_ctx_set_option(self.h, name.encode(), int(value)))
 
     def set_max_paths(self, n):
         _check(_lib.rt_ctx_set_max_paths(self.h, int(n)))

@@ -102,9 +102,11 @@ struct rt_ctx {
     DevBuf fetch; // ray-fetch counters of the stream entry points
     DevBuf coop;  // wave-private work stacks of the cooperative straggler path
     unsigned coop_cap = 2048;    // entries per wave
-    unsigned coop_steps = 2048;  // a ray is handed to its whole wave after this many loop iterations
+    unsigned coop_steps = 512;   // a ray is handed to its whole wave after this many loop iterations
     unsigned min_active[2] = {48, 48}; // [0] closest-hit, [1] any-hit launches
-    unsigned trav_mode[2] = {1, 1};    // traversal loop form per launch kind (see TraceLaunch::mode)
+    // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
+    // while-while form wins), [1] for deeper launches and the stream entry points
+    unsigned trav_mode[2] = {0, 1};
     // queues are reordered by the Morton code of the ray origin from these depths
     // on (depth of the launch that consumes the queue); 0xFFFFFFFF = never
     unsigned sort_from_depth[2] = {2, 1}; // [0] extend, [1] connect
@@ -214,6 +216,14 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
         int v = atoi(env);
         if (v == 0 || v == 1) ctx->trav_mode[0] = ctx->trav_mode[1] = (unsigned)v;
     }
+    if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
+        int v = atoi(env);
+        if (v == 0 || v == 1) ctx->trav_mode[0] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP")) {
+        int v = atoi(env);
+        if (v == 0 || v == 1) ctx->trav_mode[1] = (unsigned)v;
+    }
     if (const char *env = getenv("RTCORE_SORT_EXTEND_FROM")) ctx->sort_from_depth[0] = (unsigned)atoi(env);
     if (const char *env = getenv("RTCORE_SORT_CONNECT_FROM")) ctx->sort_from_depth[1] = (unsigned)atoi(env);
     if (const char *env = getenv("RTCORE_SORT_BITS")) {
@@ -276,6 +286,34 @@ extern "C" int rt_ctx_set_max_paths(rt_ctx *ctx, uint64_t max_paths)
     if (max_paths < 4096 || max_paths > (1ull << 30))
         return fail(RT_ERR_LIMIT, "rt_ctx_set_max_paths: %llu outside [4096, 2^30]", (unsigned long long)max_paths);
     ctx->max_paths = max_paths;
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return fail(RT_ERR_INVALID, "rt_ctx_set_option: NULL argument");
+    const std::string n(name);
+    auto in = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
+    if (n == "coop_steps") {
+        ctx->coop_steps = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
+    } else if (n == "min_active" && in(1, 64)) {
+        ctx->min_active[0] = ctx->min_active[1] = (unsigned)value;
+    } else if (n == "traversal_depth0" && in(0, 1)) {
+        ctx->trav_mode[0] = (unsigned)value;
+    } else if (n == "traversal_deep" && in(0, 1)) {
+        ctx->trav_mode[1] = (unsigned)value;
+    } else if (n == "sort_extend_from" && in(0, 0xFFFFFFFFll)) {
+        ctx->sort_from_depth[0] = (unsigned)value;
+    } else if (n == "sort_connect_from" && in(0, 0xFFFFFFFFll)) {
+        ctx->sort_from_depth[1] = (unsigned)value;
+    } else if (n == "sort_bits" && in(3, 30)) {
+        ctx->sort_bits = (unsigned)value;
+    } else if (n == "timing" && in(0, 1)) {
+        ctx->timing = value != 0;
+    } else {
+        return fail(RT_ERR_INVALID, "rt_ctx_set_option: unknown option or value out of range: %s=%lld", name,
+                    (long long)value);
+    }
     return RT_OK;
 }
 
@@ -604,7 +642,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
-                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_mode[anyhit ? 1 : 0], nullptr, nullptr, 0, 0};
+                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_mode[1], nullptr, nullptr, 0, 0};
     fill_coop(ctx, sc->dev.max_depth, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
@@ -897,7 +935,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 0, s, &slot);
                 if (rc != RT_OK) return rc;
                 TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0],
-                                ctx->trav_mode[0], perm_extend, nullptr, 0, 0};
+                                ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, nullptr, 0, 0};
                 fill_coop(ctx, sc->dev.max_depth, tle);
                 launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
                               ps.num_slots, tle, ctx->max_blocks, s);
@@ -963,7 +1001,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
                 TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1],
-                                ctx->trav_mode[1], perm_connect, nullptr, 0, 0};
+                                ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, nullptr, 0, 0};
                 fill_coop(ctx, sc->dev.max_depth, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
                                &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);

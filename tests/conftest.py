@@ -35,6 +35,19 @@ def scenes():
 
 @pytest.fixture(scope="session")
 def ctx(rt):
+    """Context with the cooperative straggler path off: a ray finished by its
+    whole wave keeps its hit distance but not its visit counters, and these
+    tests compare counters with the oracle exactly.  tests/test_gpu_coop.py
+    covers that path."""
+    c = rt.Context(0)
+    c.set_option("coop_steps", 0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_default(rt):
+    """Context with the library defaults."""
     c = rt.Context(0)
     yield c
     c.close()

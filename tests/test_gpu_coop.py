@@ -1,0 +1,87 @@
+"""The cooperative straggler path (a ray finished by all 64 lanes of its wave)
+forced onto almost every ray by a tiny step budget.
+
+That path visits nodes in another order and culls boxes against another
+running far value than the reference's depth-first walk.  The box test and the
+triangle test round differently (fused multiply-subtract on a plane vs
+Moeller-Trumbore with a division), so where two surfaces meet within rounding
+(shared edges, crossing triangles, coplanar faces) one order can cull the box of
+the marginally closer triangle and the other not.  Bar for such rays: the same
+hit/miss decision, hit distances within 2e-6 relative (a few ulps), ids equal
+wherever the distances are equal, and only a small fraction of rays affected.
+With the library default (512 steps) only rays that need more steps than that
+take this path at all."""
+import numpy as np
+import pytest
+
+from util import assert_hits_match, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("steps", [1, 7, 64])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_coop_trace_parity(O, rt, ctx_default, scenes, steps, mode):
+    ctx = ctx_default
+    ctx.set_option("coop_steps", steps)
+    ctx.set_option("traversal_deep", mode)
+    try:
+        for name, kw in (("test-mesh", {"n_tris": 20000, "seed": 3}), ("sponza-class", {}), ("cornell-class", {})):
+            sc = scenes.load(name, **kw)
+            So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+            Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+            lo, hi = float(sc.positions.min()), float(sc.positions.max())
+            rays = np.concatenate([O.generate_primary(sc.camera, 96, 54, 1),
+                                   random_rays(O.make_rays, 20000, 5, lo=lo, hi=hi)])
+            io, to, _ = So.intersect_stream(rays)
+            ig, tg, _ = Sg.intersect_stream(rays)
+            assert np.array_equal(io == rt.NO_HIT, ig == rt.NO_HIT), "hit/miss differs"
+            hit = io != rt.NO_HIT
+            rel = np.abs(tg[hit] - to[hit]) / np.maximum(np.abs(to[hit]), 1e-20)
+            assert rel.max() <= 2e-6, rel.max()
+            same_t = tg == to
+            # exact ties (coplanar overlapping faces, shared edges): either triangle of the tie
+            assert (io[same_t] != ig[same_t]).mean() < 1e-2
+            assert (~same_t).mean() < 5e-3, (~same_t).mean()
+            sh = random_rays(O.make_rays, 20000, 6, lo=lo, hi=hi, near=1e-5, far=0.4 * (hi - lo))
+            oo, _ = So.occluded1(sh)
+            og, _ = Sg.occluded_stream(sh)
+            assert np.array_equal(oo, og)
+            Sg.close()
+    finally:
+        ctx.set_option("coop_steps", 512)
+        ctx.set_option("traversal_deep", 1)
+
+
+def test_coop_render_parity(O, rt, ctx_default, scenes):
+    ctx = ctx_default
+    sc = scenes.load("test-mesh", n_tris=4000, seed=9)
+    So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+    Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+    W, H, spp, b = 80, 45, 4, 3
+    ao, sto = So.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+    try:
+        for steps in (3, 40):
+            ctx.set_option("coop_steps", steps)
+            ag, stg = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+            # a different triangle at a tie has another normal, so a handful of paths continue differently
+            assert abs(stg["total_rays"] - sto["total_rays"]) <= 1e-3 * sto["total_rays"]
+            differs = ~np.isclose(ag, ao, rtol=2e-5, atol=1e-6).all(axis=-1)
+            assert differs.mean() < 5e-3, differs.mean()
+            rmse = float(np.sqrt(np.mean((ag[..., :3] / spp - ao[..., :3] / spp) ** 2)))
+            assert rmse < 2e-3, rmse
+    finally:
+        ctx.set_option("coop_steps", 512)
+    Sg.close()
+
+
+def test_defaults_keep_hits_exact(O, rt, ctx_default, scenes):
+    """Library defaults (stragglers on) on a full-size frame of primary rays."""
+    sc = scenes.load("sponza-class")
+    So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+    Sg = rt.Scene(ctx_default, sc.positions, sc.indices, sc.geom_normals)
+    rays = O.generate_primary(sc.camera, 480, 270, 1)
+    io, to, _ = So.intersect_stream(rays)
+    ig, tg, _ = Sg.intersect_stream(rays)
+    assert_hits_match(io, to, ig, tg, "defaults")
+    Sg.close()
