@@ -84,6 +84,7 @@ struct SceneDev {
     const float *normals; // float4 per mesh triangle (xyz, 0)
     uint32_t root_ref;
     uint32_t max_depth;
+    uint32_t top_count; // nodes 0..top_count-1 are the breadth-first top of the tree (LDS-staged)
 };
 
 // Counters of src/trace_stats.rs:4-12 as kept on the device.

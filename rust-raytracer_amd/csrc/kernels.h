@@ -15,6 +15,11 @@
 
 // occupancy the trace kernels are compiled for (waves per SIMD): bounds the
 // VGPR allocation; together with the LDS stack it sets resident blocks per CU
+// inner nodes of the top of the tree staged in LDS per workgroup (0 = none).
+// The device node array is numbered so that these are nodes 0..N-1.
+#ifndef RTC_TOP_NODES
+#define RTC_TOP_NODES 0
+#endif
 #ifndef RTC_TRACE_WAVES_PER_SIMD
 #define RTC_TRACE_WAVES_PER_SIMD 5
 #endif

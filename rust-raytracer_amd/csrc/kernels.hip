@@ -128,6 +128,15 @@ __device__ __forceinline__ void block_reserve(const bool (&pred)[NQ][ITEMS], uns
 // ------------------------------------------------------------------------
 // traversal core
 
+// Inner nodes 0..top_count-1 (the breadth-first top of the tree) are copied to
+// LDS once per workgroup; a lane whose current node is one of them reads it with
+// ds_read_b128 instead of going through the vector memory path, which is the
+// busiest unit of these kernels.
+struct TopNodes {
+    const float4 *lds; // kTopNodes * 4 float4, or unused when top_count == 0
+    unsigned count;
+};
+
 struct RayRegs {
     V3 o, d, rd;   // origin, direction, 1/direction
     float near_t;  // dir_recip_near.w
@@ -168,7 +177,7 @@ struct Stack {
 
 // Moeller-Trumbore of src/triangle_opt.rs:19-42: no back-face cull, |det| <
 // f32::EPSILON rejected, u in [0,1], v >= 0, u+v <= 1; returns t or +inf.
-__device__ __forceinline__ float tri_test(const float4 t0, const float4 t1, const float4 t2, V3 o, V3 d)
+__device__ __forceinline__ float tri_test(const float4 t0, const float4 t1, const float2 t2, V3 o, V3 d)
 {
     V3 v0 = v3(t0.x, t0.y, t0.z);
     V3 e1 = v3(t0.w, t1.x, t1.y);
@@ -234,8 +243,8 @@ __device__ __forceinline__ void lane_begin(LaneState &s, const SceneDev &sc, con
 // `min_active` lanes of the wave are still traversing (the wave then goes back
 // to fetch rays for its idle lanes).
 template <bool ANYHIT, bool STATS, class STACK>
-__device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK &st, Counters &cnt,
-                                         unsigned min_active, unsigned max_steps)
+__device__ __forceinline__ void traverse(const SceneDev &sc, const TopNodes &top, LaneState &s, STACK &st,
+                                         Counters &cnt, unsigned min_active, unsigned max_steps)
 {
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
@@ -249,10 +258,21 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
         // ---- inner nodes
         while (!(cur & kLeafBit) && steps < max_steps) {
             steps++;
-            const float4 bx = nodes[(size_t)cur * 4 + 0];
-            const float4 by = nodes[(size_t)cur * 4 + 1];
-            const float4 bz = nodes[(size_t)cur * 4 + 2];
-            const float4 lk = nodes[(size_t)cur * 4 + 3];
+            float4 bx, by, bz;
+            float2 lk; // child refs only (8 of the last 16 bytes)
+            if (RTC_TOP_NODES > 0 && cur < top.count) {
+                const float4 *q = top.lds + cur * 4;
+                bx = q[0];
+                by = q[1];
+                bz = q[2];
+                lk = *reinterpret_cast<const float2 *>(q + 3);
+            } else {
+                const float4 *q = nodes + (size_t)cur * 4;
+                bx = q[0];
+                by = q[1];
+                bz = q[2];
+                lk = *reinterpret_cast<const float2 *>(q + 3);
+            }
             if (STATS) cnt.inner++;
             // near/far plane per child, picked by the sign bit of 1/d
             const float nxl = s.negx ? bx.z : bx.x, nxr = s.negx ? bx.w : bx.y;
@@ -310,7 +330,7 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
                 const size_t base = (size_t)(first + i) * 3;
                 const float4 t0 = tris[base + 0];
                 const float4 t1 = tris[base + 1];
-                const float4 t2 = tris[base + 2];
+                const float2 t2 = *reinterpret_cast<const float2 *>(tris + base + 2); // v0v2.z, id (8 of 16 B)
                 const float t = tri_test(t0, t1, t2, r.o, r.d);
                 if (t >= r.near_t && t < r.far_t) {
                     if (ANYHIT) {
@@ -344,8 +364,8 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
 // active on San-Miguel-class bounce rays).  The per-ray order of node visits
 // and triangle tests is unchanged, so results and counters are identical.
 template <bool ANYHIT, bool STATS, class STACK>
-__device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s, STACK &st, Counters &cnt,
-                                               unsigned min_active, unsigned max_steps)
+__device__ __forceinline__ void traverse_steps(const SceneDev &sc, const TopNodes &top, LaneState &s, STACK &st,
+                                               Counters &cnt, unsigned min_active, unsigned max_steps)
 {
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
     const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
@@ -375,13 +395,23 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
             }
         }
         const bool in_leaf = tri < tri_end;
-        const float4 *p = in_leaf ? tris + (size_t)tri * 3 : nodes + (size_t)cur * 4;
-        const float4 a0 = p[0];
-        const float4 a1 = p[1];
-        const float4 a2 = p[2];
+        float4 a0, a1, a2;
+        float2 lk = make_float2(0.f, 0.f); // child refs (nodes only)
+        if (RTC_TOP_NODES > 0 && !in_leaf && cur < top.count) {
+            const float4 *q = top.lds + cur * 4;
+            a0 = q[0];
+            a1 = q[1];
+            a2 = q[2];
+            lk = *reinterpret_cast<const float2 *>(q + 3);
+        } else {
+            const float4 *p = in_leaf ? tris + (size_t)tri * 3 : nodes + (size_t)cur * 4;
+            a0 = p[0];
+            a1 = p[1];
+            a2 = p[2];
+            if (!in_leaf) lk = *reinterpret_cast<const float2 *>(p + 3);
+        }
         bool need_pop = false;
         if (!in_leaf) {
-            const float4 lk = p[3];
             if (STATS) cnt.inner++;
             const float nxl = s.negx ? a0.z : a0.x, nxr = s.negx ? a0.w : a0.y;
             const float fxl = s.negx ? a0.x : a0.z, fxr = s.negx ? a0.y : a0.w;
@@ -416,7 +446,7 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
                 need_pop = true;
             }
         } else {
-            const float t = tri_test(a0, a1, a2, r.o, r.d);
+            const float t = tri_test(a0, a1, make_float2(a2.x, a2.y), r.o, r.d);
             tri++;
             if (t >= r.near_t && t < r.far_t) {
                 if (ANYHIT) {
@@ -527,7 +557,7 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
             const float4 bx = nodes[(size_t)it.ref * 4 + 0];
             const float4 by = nodes[(size_t)it.ref * 4 + 1];
             const float4 bz = nodes[(size_t)it.ref * 4 + 2];
-            const float4 lk = nodes[(size_t)it.ref * 4 + 3];
+            const float2 lk = *reinterpret_cast<const float2 *>(nodes + (size_t)it.ref * 4 + 3);
             if (STATS) cnt.inner++;
             const float nxl = negx ? bx.z : bx.x, nxr = negx ? bx.w : bx.y;
             const float fxl = negx ? bx.x : bx.z, fxr = negx ? bx.y : bx.w;
@@ -578,7 +608,7 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
                 const size_t base = (size_t)(first + i) * 3;
                 const float4 t0 = tris[base + 0];
                 const float4 t1 = tris[base + 1];
-                const float4 t2 = tris[base + 2];
+                const float2 t2 = *reinterpret_cast<const float2 *>(tris + base + 2); // v0v2.z, id (8 of 16 B)
                 const float t = tri_test(t0, t1, t2, o, d);
                 if (t >= near_t && t < lane_far) {
                     lane_far = t;
@@ -655,6 +685,7 @@ __device__ __forceinline__ void flush_stats(const Counters &cnt, unsigned long l
 
 constexpr int kBlock = RTC_TRACE_BLOCK;
 constexpr int kLdsDepth = RTC_LDS_STACK_DEPTH;
+constexpr int kTopNodes = RTC_TOP_NODES;
 
 // ------------------------------------------------------------------------
 // persistent trace kernel
@@ -745,6 +776,14 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
                                                       TraceLaunch tl)
 {
     __shared__ unsigned lds_stack[kLdsDepth * kBlock];
+    __shared__ float4 lds_top[kTopNodes > 0 ? kTopNodes * 4 : 1];
+    TopNodes top{lds_top, 0u};
+    if (kTopNodes > 0) {
+        top.count = sc.top_count < (unsigned)kTopNodes ? sc.top_count : (unsigned)kTopNodes;
+        const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+        for (unsigned i = threadIdx.x; i < top.count * 4u; i += kBlock) lds_top[i] = src[i];
+        __syncthreads();
+    }
     const unsigned n = n_ptr ? *n_ptr : n_val;
     const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
     Stack<kBlock, kLdsDepth> st;
@@ -800,9 +839,9 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
 
         // ---- traverse
         if (MODE == 0)
-            traverse<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+            traverse<ANYHIT, STATS>(sc, top, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else
-            traverse_steps<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+            traverse_steps<ANYHIT, STATS>(sc, top, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
 
         // ---- stragglers: rays that used up their step budget are finished by the whole wave
         {

@@ -457,18 +457,44 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
         big.push_back(BigLeaf{first, count});
         return kLeafBit | kBigLeafBit | (uint32_t)(big.size() - 1);
     };
-    std::vector<DevNode> dn(hb.nodes.size());
-    for (size_t i = 0; i < hb.nodes.size(); i++) {
+    // Device numbering: the first top_count nodes are the breadth-first top of the
+    // tree (staged in LDS by the trace kernels), the rest keep their pre-order
+    // sequence.  The canonical pre-order tree stays on the host (rt_scene_get_flat).
+    const size_t nn = hb.nodes.size();
+    std::vector<uint32_t> newidx(nn, 0xFFFFFFFFu);
+    uint32_t top_count = 0;
+    if (RTC_TOP_NODES > 0 && nn > 0 && !(hb.root_ref & kLeafBit)) {
+        std::vector<uint32_t> queue;
+        queue.push_back(hb.root_ref);
+        for (size_t qh = 0; qh < queue.size() && top_count < (uint32_t)RTC_TOP_NODES; qh++) {
+            const uint32_t old = queue[qh];
+            newidx[old] = top_count++;
+            const rt_flat_node &nd = hb.nodes[old];
+            if (!(nd.left & kLeafBit)) queue.push_back(nd.left);
+            if (!(nd.right & kLeafBit)) queue.push_back(nd.right);
+        }
+    }
+    {
+        uint32_t next = top_count;
+        for (size_t i = 0; i < nn; i++)
+            if (newidx[i] == 0xFFFFFFFFu) newidx[i] = next++;
+    }
+    auto map_ref = [&](uint32_t ref, uint32_t count) -> uint32_t {
+        if (ref & kLeafBit) return pack_ref(ref, count);
+        return newidx[ref];
+    };
+    std::vector<DevNode> dn(nn);
+    for (size_t i = 0; i < nn; i++) {
         const rt_flat_node &s = hb.nodes[i];
-        DevNode &d = dn[i];
+        DevNode &d = dn[newidx[i]];
         memcpy(d.bx, s.bx, sizeof d.bx);
         memcpy(d.by, s.by, sizeof d.by);
         memcpy(d.bz, s.bz, sizeof d.bz);
-        d.left = pack_ref(s.left, s.left_count);
-        d.right = pack_ref(s.right, s.right_count);
+        d.left = map_ref(s.left, s.left_count);
+        d.right = map_ref(s.right, s.right_count);
         d.pad0 = d.pad1 = 0;
     }
-    uint32_t root = pack_ref(hb.root_ref, hb.root_count);
+    uint32_t root = map_ref(hb.root_ref, hb.root_count);
     std::vector<DevTri> dt(num_triangles);
     for (uint32_t slot = 0; slot < num_triangles; slot++) {
         uint32_t t = hb.order[slot];
@@ -528,6 +554,7 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     sc->dev.normals = (const float *)sc->normals.p;
     sc->dev.root_ref = root;
     sc->dev.max_depth = hb.stats.max_depth;
+    sc->dev.top_count = top_count;
     *out = sc;
     return RT_OK;
 }
