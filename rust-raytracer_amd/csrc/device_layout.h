@@ -33,6 +33,22 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 
+// 128-byte 4-wide node: the binary tree with every other level removed.  A
+// node keeps the boxes of up to four descendants of one binary node exactly as
+// the binary nodes store them (so the slab test of a box is the same
+// arithmetic in both forms); `lo`/`hi` are [axis][child].  An unused slot has
+// the empty box (+inf, -inf) and repeats the reference of slot 0 (always a leaf
+// in such a node), so that even a ray whose slab test degenerates to NaN on
+// every axis only re-tests triangles it has already seen.
+struct alignas(128) DevWideNode {
+    float lo[3][4];
+    float hi[3][4];
+    uint32_t child[4]; // same reference encoding as DevNode; inner = wide node index
+    uint32_t bin;      // binary node this one was collapsed from
+    uint32_t pad[3];
+};
+static_assert(sizeof(DevWideNode) == 128, "DevWideNode must be 128 bytes");
+
 // 48-byte triangle in leaf order: TriangleOpt {v0v1, v0v2, v0}
 // (src/triangle_opt.rs:10-14) read as three float4, with the mesh triangle id
 // (object_indices, src/bvh.rs:32) in the spare lanes.
@@ -84,7 +100,9 @@ struct SceneDev {
     const float *normals; // float4 per mesh triangle (xyz, 0)
     uint32_t root_ref;
     uint32_t max_depth;
-    uint32_t top_count; // nodes 0..top_count-1 are the breadth-first top of the tree (LDS-staged)
+    // 4-wide form of the same tree (optional fast traversal), null when absent
+    const DevWideNode *wnodes;
+    uint32_t wroot_ref;
 };
 
 // Counters of src/trace_stats.rs:4-12 as kept on the device.

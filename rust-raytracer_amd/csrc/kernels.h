@@ -15,11 +15,6 @@
 
 // occupancy the trace kernels are compiled for (waves per SIMD): bounds the
 // VGPR allocation; together with the LDS stack it sets resident blocks per CU
-// inner nodes of the top of the tree staged in LDS per workgroup (0 = none).
-// The device node array is numbered so that these are nodes 0..N-1.
-#ifndef RTC_TOP_NODES
-#define RTC_TOP_NODES 0
-#endif
 #ifndef RTC_TRACE_WAVES_PER_SIMD
 #define RTC_TRACE_WAVES_PER_SIMD 5
 #endif
@@ -37,13 +32,16 @@ struct TraceLaunch {
     unsigned *ovf;       // traversal stack overflow area
     StatsDev *stats;
     unsigned min_active; // a wave refills when fewer lanes than this are traversing (1..64)
-    unsigned mode;       // 0 = while-while loop, 1 = one item (node or triangle) per iteration
+    unsigned mode;       // 0 = while-while loop, 1 = one item (node or triangle) per iteration,
+                         // 2 = one item per iteration on the 4-wide tree (no visit counters),
+                         // 3 = one kind of item per iteration, chosen by majority of the wave
     const unsigned *perm; // optional: process ray perm[i] at position i (queue sorted by key), or null
     // stragglers: a ray that has used coop_steps loop iterations is finished by its
     // whole wave on a wave-private work stack of coop_cap 8-byte entries (coop + wave*cap)
     void *coop;
     unsigned coop_cap;
     unsigned coop_steps; // 0xFFFFFFFF = never
+    unsigned lds_entries; // mode 3: stack entries per lane held in LDS (scene stack bound + the kDone entry)
 };
 
 // StreamRay (src/ray.rs:6-12) as three float4.

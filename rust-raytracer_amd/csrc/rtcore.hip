@@ -19,6 +19,7 @@
 
 #include "../../include/rtcore.h"
 #include "bvh_build.hpp"
+#include "wide_bvh.hpp"
 #include "device_layout.h"
 #include "kernels.h"
 
@@ -125,7 +126,9 @@ struct rt_scene {
     rt_ctx *ctx = nullptr;
     HostBvh host;
     uint32_t num_triangles = 0;
-    DevBuf nodes, tris, big, normals;
+    DevBuf nodes, wnodes, tris, big, normals;
+    uint32_t num_wide_nodes = 0;
+    uint32_t stack_bound = 0; // entries a lane's traversal stack can need on this scene
     SceneDev dev{};
     uint64_t device_bytes = 0;
     float bounds_lo[3] = {0, 0, 0};
@@ -147,11 +150,14 @@ static int ensure_overflow(rt_ctx *ctx, unsigned max_depth)
 
 // cooperative-finish settings of a launch on `sc`: off when the tree is too deep
 // for the fixed work-stack capacity
-static void fill_coop(const rt_ctx *ctx, unsigned max_depth, TraceLaunch &tl)
+static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl)
 {
     tl.coop = ctx->coop.p;
     tl.coop_cap = ctx->coop_cap;
-    tl.coop_steps = (2u * max_depth + 68u < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
+    // the work stack takes over a lane's whole traversal stack and then needs the
+    // headroom coop_finish documents
+    tl.coop_steps = (2u * sc->dev.max_depth + 68u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
+    tl.lds_entries = sc->dev.max_depth + 2u; // binary walk: one deferred sibling per level, plus entry 0
 }
 
 static int timed_begin(rt_ctx *ctx, int kind, hipStream_t s, size_t *slot)
@@ -214,15 +220,15 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL")) {
         int v = atoi(env);
-        if (v == 0 || v == 1) ctx->trav_mode[0] = ctx->trav_mode[1] = (unsigned)v;
+        if (v >= 0 && v <= 3) ctx->trav_mode[0] = ctx->trav_mode[1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
         int v = atoi(env);
-        if (v == 0 || v == 1) ctx->trav_mode[0] = (unsigned)v;
+        if (v >= 0 && v <= 3) ctx->trav_mode[0] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP")) {
         int v = atoi(env);
-        if (v == 0 || v == 1) ctx->trav_mode[1] = (unsigned)v;
+        if (v >= 0 && v <= 3) ctx->trav_mode[1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_SORT_EXTEND_FROM")) ctx->sort_from_depth[0] = (unsigned)atoi(env);
     if (const char *env = getenv("RTCORE_SORT_CONNECT_FROM")) ctx->sort_from_depth[1] = (unsigned)atoi(env);
@@ -298,9 +304,9 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->coop_steps = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
     } else if (n == "min_active" && in(1, 64)) {
         ctx->min_active[0] = ctx->min_active[1] = (unsigned)value;
-    } else if (n == "traversal_depth0" && in(0, 1)) {
+    } else if (n == "traversal_depth0" && in(0, 3)) {
         ctx->trav_mode[0] = (unsigned)value;
-    } else if (n == "traversal_deep" && in(0, 1)) {
+    } else if (n == "traversal_deep" && in(0, 3)) {
         ctx->trav_mode[1] = (unsigned)value;
     } else if (n == "sort_extend_from" && in(0, 0xFFFFFFFFll)) {
         ctx->sort_from_depth[0] = (unsigned)value;
@@ -407,6 +413,32 @@ extern "C" int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2])
 // ------------------------------------------------------------------------
 // scene
 
+// Device form of the canonical flat tree: same node order, leaf references
+// packed as device_layout.h describes.  Returns the root reference.
+static uint32_t make_dev_nodes(const rt_flat_node *nodes, size_t nn, uint32_t root_ref, uint32_t root_count,
+                               std::vector<DevNode> &dn, std::vector<BigLeaf> &big)
+{
+    auto pack_ref = [&](uint32_t ref, uint32_t count) -> uint32_t {
+        if (!(ref & kLeafBit)) return ref;
+        uint32_t first = ref & 0x7FFFFFFFu;
+        if (count >= 1 && count <= 8) return kLeafBit | (first << 3) | (count - 1);
+        big.push_back(BigLeaf{first, count});
+        return kLeafBit | kBigLeafBit | (uint32_t)(big.size() - 1);
+    };
+    dn.resize(nn);
+    for (size_t i = 0; i < nn; i++) {
+        const rt_flat_node &s = nodes[i];
+        DevNode &d = dn[i];
+        memcpy(d.bx, s.bx, sizeof d.bx);
+        memcpy(d.by, s.by, sizeof d.by);
+        memcpy(d.bz, s.bz, sizeof d.bz);
+        d.left = pack_ref(s.left, s.left_count);
+        d.right = pack_ref(s.right, s.right_count);
+        d.pad0 = d.pad1 = 0;
+    }
+    return pack_ref(root_ref, root_count);
+}
+
 extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num_vertices,
                                const uint32_t *indices, uint32_t num_triangles, const float *geom_normals,
                                rt_scene **out)
@@ -450,51 +482,8 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
 
     // device images
     std::vector<BigLeaf> big;
-    auto pack_ref = [&](uint32_t ref, uint32_t count) -> uint32_t {
-        if (!(ref & kLeafBit)) return ref;
-        uint32_t first = ref & 0x7FFFFFFFu;
-        if (count >= 1 && count <= 8) return kLeafBit | (first << 3) | (count - 1);
-        big.push_back(BigLeaf{first, count});
-        return kLeafBit | kBigLeafBit | (uint32_t)(big.size() - 1);
-    };
-    // Device numbering: the first top_count nodes are the breadth-first top of the
-    // tree (staged in LDS by the trace kernels), the rest keep their pre-order
-    // sequence.  The canonical pre-order tree stays on the host (rt_scene_get_flat).
-    const size_t nn = hb.nodes.size();
-    std::vector<uint32_t> newidx(nn, 0xFFFFFFFFu);
-    uint32_t top_count = 0;
-    if (RTC_TOP_NODES > 0 && nn > 0 && !(hb.root_ref & kLeafBit)) {
-        std::vector<uint32_t> queue;
-        queue.push_back(hb.root_ref);
-        for (size_t qh = 0; qh < queue.size() && top_count < (uint32_t)RTC_TOP_NODES; qh++) {
-            const uint32_t old = queue[qh];
-            newidx[old] = top_count++;
-            const rt_flat_node &nd = hb.nodes[old];
-            if (!(nd.left & kLeafBit)) queue.push_back(nd.left);
-            if (!(nd.right & kLeafBit)) queue.push_back(nd.right);
-        }
-    }
-    {
-        uint32_t next = top_count;
-        for (size_t i = 0; i < nn; i++)
-            if (newidx[i] == 0xFFFFFFFFu) newidx[i] = next++;
-    }
-    auto map_ref = [&](uint32_t ref, uint32_t count) -> uint32_t {
-        if (ref & kLeafBit) return pack_ref(ref, count);
-        return newidx[ref];
-    };
-    std::vector<DevNode> dn(nn);
-    for (size_t i = 0; i < nn; i++) {
-        const rt_flat_node &s = hb.nodes[i];
-        DevNode &d = dn[newidx[i]];
-        memcpy(d.bx, s.bx, sizeof d.bx);
-        memcpy(d.by, s.by, sizeof d.by);
-        memcpy(d.bz, s.bz, sizeof d.bz);
-        d.left = map_ref(s.left, s.left_count);
-        d.right = map_ref(s.right, s.right_count);
-        d.pad0 = d.pad1 = 0;
-    }
-    uint32_t root = map_ref(hb.root_ref, hb.root_count);
+    std::vector<DevNode> dn;
+    const uint32_t root = make_dev_nodes(hb.nodes.data(), hb.nodes.size(), hb.root_ref, hb.root_count, dn, big);
     std::vector<DevTri> dt(num_triangles);
     for (uint32_t slot = 0; slot < num_triangles; slot++) {
         uint32_t t = hb.order[slot];
@@ -525,11 +514,19 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
         sc->device_bytes += bytes;
         return RT_OK;
     };
+    std::vector<DevWideNode> wn;
+    uint32_t wide_depth = 0;
+    const uint32_t wroot = collapse_wide4(dn.data(), dn.size(), root, wn, &wide_depth);
+    sc->num_wide_nodes = (uint32_t)wn.size();
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
+    if (rc == RT_OK) rc = upload(sc->wnodes, wn.data(), wn.size() * sizeof(DevWideNode));
     if (rc == RT_OK) rc = upload(sc->tris, dt.data(), dt.size() * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
     if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
-    if (rc == RT_OK) rc = ensure_overflow(ctx, hb.stats.max_depth);
+    // Deepest traversal stack of a lane.  Binary walk: one deferred sibling per level.
+    // Wide walk: up to three deferred children per wide level.
+    sc->stack_bound = std::max(hb.stats.max_depth, 3u * wide_depth) + 1u;
+    if (rc == RT_OK) rc = ensure_overflow(ctx, sc->stack_bound);
     if (rc != RT_OK) {
         rt_scene_destroy(sc);
         return rc;
@@ -553,8 +550,9 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     sc->dev.big_leaves = (const BigLeaf *)sc->big.p;
     sc->dev.normals = (const float *)sc->normals.p;
     sc->dev.root_ref = root;
+    sc->dev.wnodes = (const DevWideNode *)sc->wnodes.p;
+    sc->dev.wroot_ref = wroot;
     sc->dev.max_depth = hb.stats.max_depth;
-    sc->dev.top_count = top_count;
     *out = sc;
     return RT_OK;
 }
@@ -592,12 +590,44 @@ extern "C" int rt_bvh_build_host(const float *positions, uint32_t num_vertices, 
     return RT_OK;
 }
 
+extern "C" int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref,
+                                uint32_t root_count, rt_wide_node *out, uint32_t *num_wide, uint32_t *wide_root_ref,
+                                uint32_t *wide_depth)
+{
+    if ((num_nodes && !nodes) || !num_wide || !wide_root_ref)
+        return fail(RT_ERR_INVALID, "rt_bvh_wide_host: NULL argument");
+    for (uint32_t i = 0; i < num_nodes; i++) {
+        const uint32_t refs[2] = {nodes[i].left, nodes[i].right};
+        for (uint32_t ref : refs)
+            if (!(ref & kLeafBit) && ref >= num_nodes)
+                return fail(RT_ERR_INVALID, "rt_bvh_wide_host: node %u refers to node %u of %u", i, ref, num_nodes);
+    }
+    if (!(root_ref & kLeafBit) && root_ref >= num_nodes)
+        return fail(RT_ERR_INVALID, "rt_bvh_wide_host: root %u of %u nodes", root_ref, num_nodes);
+    try {
+        std::vector<DevNode> dn;
+        std::vector<BigLeaf> big;
+        const uint32_t root = make_dev_nodes(nodes, num_nodes, root_ref, root_count, dn, big);
+        std::vector<DevWideNode> wn;
+        uint32_t depth = 0;
+        *wide_root_ref = collapse_wide4(dn.data(), dn.size(), root, wn, &depth);
+        *num_wide = (uint32_t)wn.size();
+        if (wide_depth) *wide_depth = depth;
+        static_assert(sizeof(rt_wide_node) == sizeof(DevWideNode), "rt_wide_node is the device layout");
+        if (out && !wn.empty()) memcpy(out, wn.data(), wn.size() * sizeof(DevWideNode));
+    } catch (const std::exception &ex) {
+        return fail(RT_ERR_NOMEM, "rt_bvh_wide_host: %s", ex.what());
+    }
+    return RT_OK;
+}
+
 extern "C" void rt_scene_destroy(rt_scene *sc)
 {
     if (!sc) return;
     (void)hipSetDevice(sc->ctx->device);
     (void)hipDeviceSynchronize();
     sc->nodes.release();
+    sc->wnodes.release();
     sc->tris.release();
     sc->big.release();
     sc->normals.release();
@@ -670,7 +700,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
                    ctx->min_active[anyhit ? 1 : 0], ctx->trav_mode[1], nullptr, nullptr, 0, 0};
-    fill_coop(ctx, sc->dev.max_depth, tl);
+    fill_coop(ctx, sc, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
     rc = timed_end(ctx, slot, s);
@@ -963,7 +993,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 if (rc != RT_OK) return rc;
                 TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0],
                                 ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, nullptr, 0, 0};
-                fill_coop(ctx, sc->dev.max_depth, tle);
+                fill_coop(ctx, sc, tle);
                 launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
                               ps.num_slots, tle, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
@@ -1029,7 +1059,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 if (rc != RT_OK) return rc;
                 TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1],
                                 ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, nullptr, 0, 0};
-                fill_coop(ctx, sc->dev.max_depth, tlc);
+                fill_coop(ctx, sc, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
                                &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);

@@ -1,0 +1,131 @@
+"""The 4-wide traversal form (traversal option 2) against the oracle.
+
+The wide tree regroups the binary tree's boxes, and each box and triangle test
+is the arithmetic of the binary form, so a ray tests a superset of the
+triangles the reference's walk (src/bvh/intersect_stream.rs:67-181) tests.  The
+closest-hit distance is therefore the oracle's, except for a ray that the
+binary walk culls at an intermediate box the wide tree does not have (slab
+rounding at a box face): such a ray must then agree with the oracle's brute
+force over all triangles, unless it starts on the very surface it should hit
+(t ~ 0), where either walk can lose that hit to the same rounding.  Any-hit answers follow the same rule.  Ids may differ
+on exact-distance ties."""
+import numpy as np
+import pytest
+
+from util import adversarial_rays, random_rays
+
+pytestmark = pytest.mark.gpu
+
+SCENES = (("test-mesh", {"n_tris": 20000, "seed": 3}), ("sponza-class", {}), ("cornell-class", {}),
+          ("test-mesh", {"n_tris": 7, "seed": 5}))
+
+
+def check_closest(O, sc, So, rays, io, to, ig, tg, rt, n_ordinary):
+    """The first n_ordinary rays are camera and random rays.  The rest are axis-parallel
+    rays from mesh vertices: with an infinite reciprocal the reference's slab arithmetic
+    (plane*inf - origin*inf) gives +-inf or NaN by the sign of the plane coordinate, so
+    whether a box passes depends on the far value at that moment and with it on the visit
+    order.  For those rays only soundness is required: a reported hit is a real
+    intersection of that triangle and nothing closer is claimed than brute force finds."""
+    diff = np.flatnonzero(tg != to)
+    ordinary = diff[diff < n_ordinary]
+    assert ordinary.size <= max(2, 1e-4 * n_ordinary), "%d of %d rays differ" % (ordinary.size, n_ordinary)
+    if ordinary.size:  # the wide form found the true closest hit that the binary walk culled
+        ib, tb = So.intersect_brute(rays[ordinary])
+        assert np.array_equal(tg[ordinary], tb), (tg[ordinary], to[ordinary], tb)
+    special = diff[diff >= n_ordinary]
+    if special.size:
+        ib, tb = So.intersect_brute(rays[special])
+        assert (tb <= tg[special]).all()
+        P, I = sc.positions, sc.indices
+        for i in special:
+            if ig[i] == rt.NO_HIT:
+                assert np.isinf(tg[i])
+                continue
+            v0, v1, v2 = P[I[ig[i]]]
+            t = O.tri_intersect(v0, v1 - v0, v2 - v0, rays[i]["origin_far"][:3], rays[i]["direction"][:3])
+            assert np.float32(t) == tg[i]
+    same = tg == to
+    assert np.array_equal((io == rt.NO_HIT)[same], (ig == rt.NO_HIT)[same])
+    assert (io[same] != ig[same]).mean() < 1e-2  # exact ties only
+    return int(diff.size)
+
+
+@pytest.mark.parametrize("coop", [0, 5, 512])
+def test_wide_trace_parity(O, rt, ctx_default, scenes, coop):
+    ctx = ctx_default
+    ctx.set_option("traversal_deep", 2)
+    ctx.set_option("coop_steps", coop)
+    try:
+        for name, kw in SCENES:
+            sc = scenes.load(name, **kw)
+            So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+            Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+            lo, hi = float(sc.positions.min()), float(sc.positions.max())
+            ordinary = np.concatenate([O.generate_primary(sc.camera, 96, 54, 1),
+                                       random_rays(O.make_rays, 30000, 5, lo=lo, hi=hi)])
+            rays = np.concatenate([ordinary, adversarial_rays(O.make_rays, sc.positions)])
+            io, to, _ = So.intersect_stream(rays)
+            ig, tg, st = Sg.intersect_stream(rays, stats=False)
+            if coop == 5:
+                # forced wave-cooperative finish: distances within a few ulps (other cull order)
+                n = ordinary.size
+                hit = io[:n] != rt.NO_HIT
+                assert np.array_equal(hit, ig[:n] != rt.NO_HIT)
+                rel = np.abs(tg[:n][hit] - to[:n][hit]) / np.maximum(np.abs(to[:n][hit]), 1e-20)
+                assert rel.max() <= 2e-6
+            else:
+                check_closest(O, sc, So, rays, io, to, ig, tg, rt, ordinary.size)
+            sh = random_rays(O.make_rays, 30000, 6, lo=lo, hi=hi, near=1e-5, far=0.4 * (hi - lo))
+            oo, _ = So.occluded1(sh)
+            og, _ = Sg.occluded_stream(sh, stats=False)
+            bad = np.flatnonzero(oo != og)
+            assert bad.size <= 2
+            if bad.size:  # the wide form may only find an occluder the binary walk culled, never lose one
+                ib, _ = So.intersect_brute(sh[bad])
+                assert np.array_equal(og[bad].astype(bool), ib != rt.NO_HIT)
+            Sg.close()
+    finally:
+        ctx.set_option("coop_steps", 512)
+        ctx.set_option("traversal_deep", 1)
+
+
+def test_wide_stats_request_runs_binary_form(O, rt, ctx, scenes):
+    """Visit counters are defined by the binary walk: a call that asks for them gets that walk."""
+    ctx.set_option("traversal_deep", 2)
+    try:
+        sc = scenes.load("test-mesh", n_tris=5000, seed=8)
+        So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+        Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+        rays = random_rays(O.make_rays, 5000, 2)
+        io, to, so = So.intersect_stream(rays)
+        ig, tg, sg = Sg.intersect_stream(rays, stats=True)
+        assert np.array_equal(to, tg)
+        for k in ("total_rays", "inner_rays", "leaf_rays", "obj_intersect"):
+            assert so[k] == sg[k], k
+        Sg.close()
+    finally:
+        ctx.set_option("traversal_deep", 1)
+
+
+@pytest.mark.parametrize("name,kw,W,H,spp,b", [("cornell-class", {}, 96, 54, 4, 2),
+                                               ("test-mesh", {"n_tris": 4000, "seed": 9}, 80, 45, 4, 3)])
+def test_wide_render_parity(O, rt, ctx_default, scenes, name, kw, W, H, spp, b):
+    ctx = ctx_default
+    sc = scenes.load(name, **kw)
+    So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+    Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+    ao, sto = So.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+    ctx.set_option("traversal_depth0", 2)
+    ctx.set_option("traversal_deep", 2)
+    try:
+        ag, stg = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+    finally:
+        ctx.set_option("traversal_depth0", 0)
+        ctx.set_option("traversal_deep", 1)
+    assert abs(stg["total_rays"] - sto["total_rays"]) <= 1e-3 * sto["total_rays"]
+    differs = ~np.isclose(ag, ao, rtol=2e-5, atol=1e-6).all(axis=-1)
+    assert differs.mean() < 5e-3, differs.mean()
+    rmse = float(np.sqrt(np.mean((ag[..., :3] / spp - ao[..., :3] / spp) ** 2)))
+    assert rmse < 2e-3, rmse
+    Sg.close()

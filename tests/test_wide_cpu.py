@@ -1,0 +1,95 @@
+"""Host-side invariants of the 4-wide collapse (rt_bvh_wide_host): it only
+regroups the boxes of the binary tree that the reference builds
+(src/bvh/build.rs:45-207), so every child box must be a child box of some
+binary node, bit for bit, and the leaves must be the binary tree's leaves, each
+exactly once, in the same left-to-right order."""
+import numpy as np
+import pytest
+
+LEAF = 0x80000000
+
+
+def pack(ref, count):
+    if not ref & LEAF:
+        return None
+    assert 1 <= count <= 8
+    return LEAF | ((ref & 0x7FFFFFFF) << 3) | (count - 1)
+
+
+def binary_leaves(nodes, root):
+    """Leaf references (device packing) left to right, and per binary node its two child boxes."""
+    out = []
+    stack = [(root, 0)]
+    while stack:
+        ref, cnt = stack.pop()
+        if ref & LEAF:
+            out.append(pack(ref, cnt))
+            continue
+        n = nodes[ref]
+        stack.append((int(n["right"]), int(n["right_count"])))
+        stack.append((int(n["left"]), int(n["left_count"])))
+    return out
+
+
+@pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 3000, "seed": 4}),
+                                     ("test-mesh", {"n_tris": 9, "seed": 1}), ("test-mesh", {"n_tris": 5, "seed": 2})])
+def test_wide_collapse_invariants(rt, scenes, name, kw):
+    sc = scenes.load(name, **kw)
+    nodes, order, info, stats = rt.build_bvh_host(sc.positions, sc.indices)
+    wide, wroot, wdepth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
+    if info["root_ref"] & LEAF:
+        assert len(wide) == 0 and wroot == pack(info["root_ref"], info["root_count"])
+        return
+    assert wroot == 0 and 1 <= len(wide) <= len(nodes)
+    assert wdepth <= stats["max_depth"]
+
+    # box of every binary child, keyed by the device reference of that child
+    boxes = {}
+    for i, n in enumerate(nodes):
+        for side, lane in (("left", 0), ("right", 1)):
+            ref = int(n[side])
+            key = pack(ref, int(n[side + "_count"])) if ref & LEAF else ref
+            lo = (n["bx"][lane], n["by"][lane], n["bz"][lane])
+            hi = (n["bx"][lane + 2], n["by"][lane + 2], n["bz"][lane + 2])
+            boxes[key] = (np.array(lo, np.float32), np.array(hi, np.float32))
+
+    leaves = []
+    seen_inner = set()
+
+    def walk(w):
+        node = wide[w]
+        used = [i for i in range(4) if np.isfinite(node["lo"][0][i])]
+        assert used == list(range(len(used))) and len(used) >= 2
+        for i in range(4):
+            ref = int(node["child"][i])
+            if i not in used:
+                assert np.all(node["lo"][:, i] == np.inf) and np.all(node["hi"][:, i] == -np.inf)
+                assert ref == int(node["child"][0]) and ref & LEAF
+                continue
+            if ref & LEAF:
+                key = ref
+                leaves.append(ref)
+            else:
+                key = int(wide[ref]["bin"])  # a wide child stands for the binary node it came from
+            lo, hi = boxes[key]
+            assert np.array_equal(node["lo"][:, i], lo) and np.array_equal(node["hi"][:, i], hi)
+            if not ref & LEAF:
+                assert ref not in seen_inner and ref > w  # pre-order numbering
+                seen_inner.add(ref)
+                walk(ref)
+        if len(used) < 4:
+            assert all(int(node["child"][i]) & LEAF for i in used)
+
+    walk(0)
+    assert int(wide[0]["bin"]) == info["root_ref"]
+    assert len(seen_inner) == len(wide) - 1
+    assert leaves == binary_leaves(nodes, info["root_ref"])
+
+
+def test_wide_host_rejects_bad_tree(rt):
+    nodes = np.zeros(1, dtype=rt.NODE_DTYPE)
+    nodes[0]["left"] = 5  # inner reference beyond the array
+    nodes[0]["right"] = LEAF
+    nodes[0]["right_count"] = 1
+    with pytest.raises(rt.RtError):
+        rt.wide_bvh_host(nodes, 0, 0)
