@@ -152,11 +152,17 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       hit distance; their visit counters and the id on an
  *                       exact-distance tie may differ from the single-lane walk.
  *   "min_active"        1..64, a wave fetches new rays when fewer lanes are busy
- *   "traversal_depth0", "traversal_deep"   loop form of depth-0 launches / of deeper launches
- *                       and the stream entry points: 0 = while-while loop on the binary
- *                       tree, 1 = one item (node or triangle) per iteration on the binary
- *                       tree, 2 = one item per iteration on the 4-wide tree.  Calls that
- *                       ask for visit counters always run form 0 or 1.
+ *   "traversal_depth0", "traversal_deep", "traversal_stream"   traversal form of the
+ *                       depth-0 launches of rt_render, of its deeper launches, and of the
+ *                       stream entry points: 0 = while-while loop on the binary tree, 1 = one
+ *                       item (node or triangle) per iteration on the binary tree, 2 = one
+ *                       item per iteration on the quantized 4-wide tree, 3 = while-while loop
+ *                       on the quantized 4-wide tree.  Defaults 3, 2, 1.  Forms 0 and 1 walk
+ *                       the reference's tree in the reference's order (exact distances, ids
+ *                       and visit counters); 2 and 3 test a superset of its triangles in
+ *                       another order: same distances except where two surfaces meet within
+ *                       rounding, ids may differ on exact ties, no visit counters.  Calls
+ *                       that ask for visit counters always run form 0 or 1.
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
  *   "sort_bits"         3..30 key bits that take part in the order
  *   "timing"            0/1 per-launch HIP events */
@@ -190,14 +196,23 @@ int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint3
                       rt_scene_info *info, rt_bvh_stats *stats);
 
 /* 4-wide traversal form of the tree (no counterpart in the reference, whose tree
- * is binary, src/bvh.rs:19-34).  lo/hi are [axis][child]: the boxes of up to
+ * is binary, src/bvh.rs:19-34).
+ *
+ * rt_wide_node is the exact form: lo/hi are [axis][child], the boxes of up to
  * four descendants of one binary node, copied bit for bit from the binary
  * nodes.  Child references: bit 31 clear = wide node index; bit 31 set = leaf,
  * with bit 30 clear: bits 3..29 = first slot in the leaf-ordered triangle
  * array and bits 0..2 = count-1; bit 30 set: low 30 bits number the leaves of
  * more than 8 triangles (src/bvh/build.rs:93-101) in node order.  An unused
  * slot has lo = +inf, hi = -inf and repeats child[0].  bin = index of the
- * canonical binary node the wide node was collapsed from. */
+ * canonical binary node the wide node was collapsed from.
+ *
+ * rt_qwide_node (64 bytes) is the form the device traverses: the same node
+ * with its child boxes on an 8-bit grid, plane = origin[axis] + byte *
+ * scale[axis], child i in byte i of lo[axis] / hi[axis], every box rounded
+ * outward (by at least 2^-19 of the node's largest coordinate or extent), so a
+ * ray that meets an exact child box meets the quantized one.  Unused slots have
+ * lo byte 255 and hi byte 0. */
 typedef struct rt_wide_node {
     float lo[3][4];
     float hi[3][4];
@@ -206,14 +221,23 @@ typedef struct rt_wide_node {
     uint32_t pad[3];
 } rt_wide_node;
 
-/* Derives the 4-wide form from a canonical flat tree on the host: children of
+typedef struct rt_qwide_node {
+    float origin[3];
+    float scale[3];
+    uint32_t lo[3];
+    uint32_t hi[3];
+    uint32_t child[4];
+} rt_qwide_node;
+
+/* Derives the 4-wide forms from a canonical flat tree on the host: children of
  * inner children are pulled up, largest surface area first, until a node has
- * four.  out may be NULL (count only) and otherwise holds num_nodes entries
+ * four.  out and qout may be NULL and otherwise hold num_nodes entries each
  * (the wide tree never has more nodes than the binary one); nodes are written
  * in depth-first pre-order.  wide_root_ref is 0, or the leaf reference when the
  * root is a leaf.  rt_scene_create runs the same code. */
 int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref, uint32_t root_count,
-                     rt_wide_node *out, uint32_t *num_wide, uint32_t *wide_root_ref, uint32_t *wide_depth);
+                     rt_wide_node *out, rt_qwide_node *qout, uint32_t *num_wide, uint32_t *wide_root_ref,
+                     uint32_t *wide_depth);
 
 /* Bvh::intersect_stream, src/bvh/intersect_stream.rs:10-15: closest hit for n
  * rays.  hits[i] = mesh triangle id or RT_NO_HIT; rays[i].origin_far[3] is

@@ -32,6 +32,8 @@ NODE_DTYPE = np.dtype([("bx", np.float32, 4), ("by", np.float32, 4), ("bz", np.f
                        ("left_count", np.uint32), ("right_count", np.uint32)])
 WIDE_DTYPE = np.dtype([("lo", np.float32, (3, 4)), ("hi", np.float32, (3, 4)), ("child", np.uint32, 4),
                        ("bin", np.uint32), ("pad", np.uint32, 3)])
+QWIDE_DTYPE = np.dtype([("origin", np.float32, 3), ("scale", np.float32, 3), ("lo", np.uint32, 3),
+                        ("hi", np.uint32, 3), ("child", np.uint32, 4)])
 TRI_DTYPE = np.dtype([("v0", np.float32, 3), ("v0v1", np.float32, 3), ("v0v2", np.float32, 3),
                       ("id", np.uint32), ("pad", np.uint32, 2)])
 
@@ -106,7 +108,7 @@ EXPORTS = {
     "rt_scene_destroy": (None, [_vp]),
     "rt_bvh_build_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
                                     C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
-    "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.POINTER(C.c_uint32),
+    "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32),
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_scene_stats": (C.c_int, [_vp, C.POINTER(BvhStats)]),
     "rt_scene_get_info": (C.c_int, [_vp, C.POINTER(SceneInfo)]),
@@ -183,13 +185,15 @@ def build_bvh_host(positions, indices, threads=0):
 
 
 def wide_bvh_host(nodes, root_ref, root_count):
-    """rt_bvh_wide_host: 4-wide form of a canonical flat tree -> (wide nodes, wide root ref, wide depth)."""
+    """rt_bvh_wide_host: 4-wide forms of a canonical flat tree ->
+    (exact wide nodes, quantized wide nodes, wide root ref, wide depth)."""
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     out = np.zeros(max(len(nodes), 1), dtype=WIDE_DTYPE)
+    qout = np.zeros(max(len(nodes), 1), dtype=QWIDE_DTYPE)
     n, root, depth = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    _check(_lib.rt_bvh_wide_host(_p(nodes), len(nodes), int(root_ref), int(root_count), _p(out), C.byref(n),
-                                 C.byref(root), C.byref(depth)))
-    return out[:n.value].copy(), int(root.value), int(depth.value)
+    _check(_lib.rt_bvh_wide_host(_p(nodes), len(nodes), int(root_ref), int(root_count), _p(out), _p(qout),
+                                 C.byref(n), C.byref(root), C.byref(depth)))
+    return out[:n.value].copy(), qout[:n.value].copy(), int(root.value), int(depth.value)
 
 
 class Context:

@@ -33,13 +33,13 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 
-// 128-byte 4-wide node: the binary tree with every other level removed.  A
-// node keeps the boxes of up to four descendants of one binary node exactly as
-// the binary nodes store them (so the slab test of a box is the same
-// arithmetic in both forms); `lo`/`hi` are [axis][child].  An unused slot has
-// the empty box (+inf, -inf) and repeats the reference of slot 0 (always a leaf
-// in such a node), so that even a ray whose slab test degenerates to NaN on
-// every axis only re-tests triangles it has already seen.
+// 4-wide form: the binary tree with every other level removed.  A wide node
+// holds up to four descendants of one binary node.
+//
+// DevWideNode (128 bytes) is the exact form the host builds first: every child
+// box is a child box of some binary node, bit for bit; `lo`/`hi` are
+// [axis][child].  An unused slot has the empty box (+inf, -inf) and repeats the
+// reference of slot 0 (always a leaf in such a node).
 struct alignas(128) DevWideNode {
     float lo[3][4];
     float hi[3][4];
@@ -48,6 +48,24 @@ struct alignas(128) DevWideNode {
     uint32_t pad[3];
 };
 static_assert(sizeof(DevWideNode) == 128, "DevWideNode must be 128 bytes");
+
+// DevQWideNode (64 bytes) is what the traversal reads: the four child boxes on an
+// 8-bit grid local to the node, plane = origin[axis] + byte * scale[axis], each
+// box rounded OUTWARD by at least the margin the builder documents.  A ray that
+// meets an exact child box therefore meets its quantized box, so the leaves
+// reached are a superset of those of the exact tree and the triangle tests
+// decide the hit as before.  Byte i of every lo/hi word belongs to child i.  An
+// unused slot has lo = 255, hi = 0 on every axis (scale > 0 always, so near >
+// far) and repeats the reference of slot 0, so that even a ray whose slab test
+// degenerates to NaN on every axis only re-tests triangles it has already seen.
+struct alignas(64) DevQWideNode {
+    float origin[3];
+    float scale[3];
+    uint32_t lo[3]; // [axis], child i in byte i
+    uint32_t hi[3];
+    uint32_t child[4];
+};
+static_assert(sizeof(DevQWideNode) == 64, "DevQWideNode must be 64 bytes");
 
 // 48-byte triangle in leaf order: TriangleOpt {v0v1, v0v2, v0}
 // (src/triangle_opt.rs:10-14) read as three float4, with the mesh triangle id
@@ -100,8 +118,9 @@ struct SceneDev {
     const float *normals; // float4 per mesh triangle (xyz, 0)
     uint32_t root_ref;
     uint32_t max_depth;
-    // 4-wide form of the same tree (optional fast traversal), null when absent
-    const DevWideNode *wnodes;
+    // 4-wide quantized form of the same tree (optional fast traversal), null when absent
+    const DevQWideNode *wnodes;
+    const uint32_t *wbin; // per wide node: the binary node it was collapsed from
     uint32_t wroot_ref;
 };
 

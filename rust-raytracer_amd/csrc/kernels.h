@@ -33,15 +33,14 @@ struct TraceLaunch {
     StatsDev *stats;
     unsigned min_active; // a wave refills when fewer lanes than this are traversing (1..64)
     unsigned mode;       // 0 = while-while loop, 1 = one item (node or triangle) per iteration,
-                         // 2 = one item per iteration on the 4-wide tree (no visit counters),
-                         // 3 = one kind of item per iteration, chosen by majority of the wave
+                         // 2 = one item per iteration on the quantized 4-wide tree, 3 = while-while loop on it
+                         // (no visit counters in 2 and 3)
     const unsigned *perm; // optional: process ray perm[i] at position i (queue sorted by key), or null
     // stragglers: a ray that has used coop_steps loop iterations is finished by its
     // whole wave on a wave-private work stack of coop_cap 8-byte entries (coop + wave*cap)
     void *coop;
     unsigned coop_cap;
     unsigned coop_steps; // 0xFFFFFFFF = never
-    unsigned lds_entries; // mode 3: stack entries per lane held in LDS (scene stack bound + the kDone entry)
 };
 
 // StreamRay (src/ray.rs:6-12) as three float4.

@@ -144,8 +144,6 @@ struct Counters {
 // [entry][thread] order (lane l and lane l+32 hit the same bank in different
 // halves of a ds_read_b32, so accesses are conflict-free); deeper entries go to
 // a global overflow area laid out the same way.
-constexpr int kAllLds = 0x7FFFFFFF; // LDS_DEPTH value of a stack that never leaves LDS
-
 template <int BLOCK, int LDS_DEPTH>
 struct Stack {
     unsigned *lds;      // &shared[threadIdx.x]
@@ -163,14 +161,14 @@ struct Stack {
     // writes entry `at` without moving the stack pointer
     __device__ __forceinline__ void store(int at, unsigned v)
     {
-        if (LDS_DEPTH == kAllLds || at < LDS_DEPTH)
+        if (at < LDS_DEPTH)
             lds[at * BLOCK] = v;
         else
             ovf[(size_t)(at - LDS_DEPTH) * ovf_stride] = v;
     }
     __device__ __forceinline__ unsigned load(int at) const
     {
-        if (LDS_DEPTH == kAllLds || at < LDS_DEPTH) return lds[at * BLOCK];
+        if (at < LDS_DEPTH) return lds[at * BLOCK];
         return ovf[(size_t)(at - LDS_DEPTH) * ovf_stride];
     }
     __device__ __forceinline__ unsigned pop()
@@ -492,126 +490,27 @@ __device__ __forceinline__ float vmin3(float a, float b, float c)
     return r;
 }
 
-__device__ __forceinline__ float2 ld_f2(const char *__restrict__ base, unsigned byte_off)
+// The four 16-byte loads of one traversal item as exactly four vector memory
+// instructions: bytes 0..47 for every active lane (node or triangle), bytes
+// 48..63 only for the lanes of `node_mask`.  Written out because the compiler
+// trims the third load to the 8 bytes a triangle needs and then covers the rest
+// of a node with two more instructions, and the instruction count is what the
+// kernel is bound by.
+__device__ __forceinline__ void load_item(const float4 *p, unsigned long long node_mask, float4 &a0, float4 &a1,
+                                          float4 &a2, uint4 &a3)
 {
-    return *reinterpret_cast<const float2 *>(base + byte_off);
-}
-
-// Phase-voting form of the binary traversal.  A lane is either at an inner node
-// or inside a leaf; every iteration the wave runs ONE of the two code paths, the
-// one more of its lanes are waiting for, and the other lanes sit the iteration
-// out.  Against the stepwise form (both paths every iteration, each at the
-// occupancy of its own lanes) the vector unit spends its issue slots on the
-// majority only, and against the while-while form no lane waits for the last
-// lane of the other kind.  Per ray the sequence of node visits and triangle
-// tests is the one of the other two forms, so results and counters are the same.
-//
-// The node step reads the near and the far plane pair of each axis directly
-// (the sign of 1/d picks the 8-byte half of the axis row, the blendv of
-// src/bvh/intersect_stream.rs:116-121 done by addressing), and the stack keeps
-// kDone in entry 0 so that a pop needs no emptiness test.
-template <bool ANYHIT, bool STATS, class STACK>
-__device__ __forceinline__ void traverse_vote(const SceneDev &sc, LaneState &s, STACK &st, Counters &cnt,
-                                              unsigned min_active, unsigned max_steps)
-{
-    const char *__restrict__ nb = reinterpret_cast<const char *>(sc.nodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
-    RayRegs &r = s.r;
-    unsigned cur = s.cur, tri = s.tri, tri_end = s.tri_end;
-    unsigned steps = s.steps;
-    int sp = st.sp;
-    const unsigned nox = s.negx ? 8u : 0u, noy = s.negy ? 24u : 16u, noz = s.negz ? 40u : 32u;
-    const float rx = r.rd.x, ry = r.rd.y, rz = r.rd.z;
-    const float ox = -s.ordx, oy = -s.ordy, oz = -s.ordz;
-
-    while (cur != kDone && (steps < max_steps || tri < tri_end)) {
-        if ((cur & kLeafBit) && tri >= tri_end) { // entering a leaf
-            unsigned first, count;
-            if (cur & kBigLeafBit) {
-                const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
-                first = bl.first;
-                count = bl.count;
-            } else {
-                first = (cur >> 3) & (kMaxPackedFirst - 1u);
-                count = (cur & 7u) + 1u;
-            }
-            tri = first;
-            tri_end = first + count;
-            if (STATS) {
-                cnt.leaf++;
-                cnt.tris += count;
-            }
-        }
-        const bool in_leaf = tri < tri_end;
-        const unsigned n_leaf = (unsigned)__popcll(__ballot(in_leaf)), n_all = (unsigned)__popcll(__ballot(true));
-        if (2u * n_leaf <= n_all) {
-            if (!in_leaf) {
-                steps++;
-                if (STATS) cnt.inner++;
-                const unsigned a = cur << 6;
-                const float2 nx = ld_f2(nb, a + nox), fx = ld_f2(nb, a + (nox ^ 8u));
-                const float2 ny = ld_f2(nb, a + noy), fy = ld_f2(nb, a + (noy ^ 8u));
-                const float2 nz = ld_f2(nb, a + noz), fz = ld_f2(nb, a + (noz ^ 8u));
-                const float2 lk = ld_f2(nb, a + 48u);
-                const float nearl = vmax3(__fmaf_rn(nx.x, rx, ox), __fmaf_rn(ny.x, ry, oy),
-                                          vmax(__fmaf_rn(nz.x, rz, oz), r.near_t));
-                const float nearr = vmax3(__fmaf_rn(nx.y, rx, ox), __fmaf_rn(ny.y, ry, oy),
-                                          vmax(__fmaf_rn(nz.y, rz, oz), r.near_t));
-                const float farl = vmin3(__fmaf_rn(fx.x, rx, ox), __fmaf_rn(fy.x, ry, oy),
-                                         vmin(__fmaf_rn(fz.x, rz, oz), r.far_t));
-                const float farr = vmin3(__fmaf_rn(fx.y, rx, ox), __fmaf_rn(fy.y, ry, oy),
-                                         vmin(__fmaf_rn(fz.y, rz, oz), r.far_t));
-                // the three compare results stay wave masks and are combined on the scalar unit
-                const unsigned long long mhl = __builtin_amdgcn_ballot_w64(nearl <= farl);
-                const unsigned long long mhr = __builtin_amdgcn_ballot_w64(nearr <= farr);
-                const unsigned long long mlf =
-                    ANYHIT ? ~0ull : __builtin_amdgcn_ballot_w64(nearl <= nearr); // left first on ties
-                const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
-                const bool go_left = __builtin_amdgcn_inverse_ballot_w64(mhl & (mlf | ~mhr));
-                const bool both = __builtin_amdgcn_inverse_ballot_w64(mhl & mhr);
-                const bool none = __builtin_amdgcn_inverse_ballot_w64(~(mhl | mhr));
-                cur = go_left ? left : right;
-                // the deferred child is written whether or not it is kept: the slot above the
-                // top of the stack is free, and only the pointer move depends on `both`
-                st.store(sp, go_left ? right : left);
-                int sp_pushed; // opaque add: keeps the update a select on the compare masks
-                asm("v_add_u32 %0, 1, %1" : "=v"(sp_pushed) : "v"(sp));
-                sp = both ? sp_pushed : sp;
-                if (none) {
-                    sp--;
-                    cur = st.load(sp); // entry 0 holds kDone
-                }
-            }
-        } else if (in_leaf) {
-            steps++;
-            const size_t base = (size_t)tri * 3;
-            const float4 t0 = tris[base + 0];
-            const float4 t1 = tris[base + 1];
-            const float2 t2 = *reinterpret_cast<const float2 *>(tris + base + 2); // v0v2.z, id (8 of 16 B)
-            const float t = tri_test(t0, t1, t2, r.o, r.d);
-            tri++;
-            if (t >= r.near_t && t < r.far_t) {
-                if (ANYHIT) {
-                    s.hit = 1u;
-                    cur = kDone;
-                    tri = tri_end;
-                } else {
-                    r.far_t = t;
-                    s.hit = __float_as_uint(t2.y);
-                }
-            }
-            if (tri >= tri_end && cur != kDone) {
-                sp--;
-                cur = st.load(sp);
-            }
-        }
-        if (n_all < min_active) break;
-    }
-    s.cur = cur;
-    s.tri = tri;
-    s.tri_end = tri_end;
-    s.steps = steps;
-    st.sp = sp;
+    unsigned long long saved;
+    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
+                 "s_mov_b64 %4, exec\n\t"
+                 "s_and_b64 exec, exec, %6\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&s"(saved)
+                 : "v"(p), "s"(node_mask)
+                 : "memory", "scc");
 }
 
 // compare-exchange of two (entry distance, child reference) pairs
@@ -626,28 +525,108 @@ __device__ __forceinline__ void traverse_vote(const SceneDev &sc, LaneState &s, 
         ca = ct_;                               \
     }
 
-// Stepwise traversal of the 4-wide tree: an iteration handles one wide node
-// (four child boxes) or one triangle.  Each box test is the arithmetic of the
-// binary form on the same box; the hit children are visited nearest first (ties
-// in slot order = left to right) and the others are deferred nearest on top, so a
-// ray meets the leaves in the order the binary form gives it whenever boxes do
-// not overlap.  Closest-hit distances are those of the binary form except for a
-// ray that the binary form culls at an intermediate box which the wide form does
-// not have (a rounding effect at box faces): there the wide form reports the hit.
-// No visit counters in this form.
+// One quantized wide node: tests the four child boxes, moves `cur` to the first
+// child to visit and defers the others; returns true when no child is hit (the
+// caller pops).
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ bool qwide_step(const float4 a0, const float4 a1, const float4 a2, const uint4 ch,
+                                           const LaneState &s, STACK &st, unsigned &cur)
+{
+    const RayRegs &r = s.r;
+    const float inf = __builtin_inff();
+    // a0 = origin.xyz, scale.x; a1 = scale.yz, lo.x, lo.y; a2 = lo.z, hi.x, hi.y, hi.z
+    const unsigned lox = __float_as_uint(a1.z), loy = __float_as_uint(a1.w), loz = __float_as_uint(a2.x);
+    const unsigned hix = __float_as_uint(a2.y), hiy = __float_as_uint(a2.z), hiz = __float_as_uint(a2.w);
+    const unsigned nxw = s.negx ? hix : lox, fxw = s.negx ? lox : hix;
+    const unsigned nyw = s.negy ? hiy : loy, fyw = s.negy ? loy : hiy;
+    const unsigned nzw = s.negz ? hiz : loz, fzw = s.negz ? loz : hiz;
+    const float sx = a0.w * r.rd.x, sy = a1.x * r.rd.y, sz = a1.y * r.rd.z;
+    const float bx = __fmaf_rn(a0.x, r.rd.x, -s.ordx), by = __fmaf_rn(a0.y, r.rd.y, -s.ordy),
+                bz = __fmaf_rn(a0.z, r.rd.z, -s.ordz);
+#define RTC_BYTE(w, i) ((float)(((w) >> (8 * (i))) & 0xFFu))
+#define RTC_NEAR(i)                                                                                  \
+        vmax3(__fmaf_rn(RTC_BYTE(nxw, i), sx, bx), __fmaf_rn(RTC_BYTE(nyw, i), sy, by),                  \
+        vmax(__fmaf_rn(RTC_BYTE(nzw, i), sz, bz), r.near_t))
+#define RTC_FAR(i)                                                                                   \
+        vmin3(__fmaf_rn(RTC_BYTE(fxw, i), sx, bx), __fmaf_rn(RTC_BYTE(fyw, i), sy, by),                  \
+        vmin(__fmaf_rn(RTC_BYTE(fzw, i), sz, bz), r.far_t))
+    const float n0 = RTC_NEAR(0), f0 = RTC_FAR(0);
+    const float n1 = RTC_NEAR(1), f1 = RTC_FAR(1);
+    const float n2 = RTC_NEAR(2), f2 = RTC_FAR(2);
+    const float n3 = RTC_NEAR(3), f3 = RTC_FAR(3);
+#undef RTC_NEAR
+#undef RTC_FAR
+#undef RTC_BYTE
+    float k0 = n0 <= f0 ? n0 : inf;
+    float k1 = n1 <= f1 ? n1 : inf;
+    float k2 = n2 <= f2 ? n2 : inf;
+    float k3 = n3 <= f3 ? n3 : inf;
+    unsigned c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+    if (!ANYHIT) { // stable 4-input sorting network on the entry distance
+        RTC_CE(k0, c0, k1, c1);
+        RTC_CE(k2, c2, k3, c3);
+        RTC_CE(k0, c0, k2, c2);
+        RTC_CE(k1, c1, k3, c3);
+        RTC_CE(k1, c1, k2, c2);
+        if (k0 < inf) {
+            cur = c0;
+            const int n = (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
+            if (n == 3) st.store(st.sp, c3);
+            if (n >= 2) st.store(st.sp + n - 2, c2);
+            if (n >= 1) st.store(st.sp + n - 1, c1);
+            st.sp += n;
+        } else {
+            return true;
+        }
+    } else {
+        // any-hit: the answer does not depend on the order; take the hit children in slot
+        // order (src/bvh/intersect1.rs:7-106 goes left first as well)
+        unsigned next = kDone;
+        if (k3 < inf) next = c3;
+        if (k2 < inf) {
+            if (next != kDone) st.push(next);
+            next = c2;
+        }
+        if (k1 < inf) {
+            if (next != kDone) st.push(next);
+            next = c1;
+        }
+        if (k0 < inf) {
+            if (next != kDone) st.push(next);
+            next = c0;
+        }
+        if (next != kDone)
+            cur = next;
+        else
+            return true;
+    }
+    return false;
+}
+
+// Stepwise traversal of the quantized 4-wide tree: an iteration handles one
+// wide node (four child boxes, 64 bytes) or one triangle, and the first three
+// 16-byte loads are shared by both kinds of item, so an iteration costs four
+// vector memory instructions whatever the lanes are doing -- and a wide node
+// stands for about 2.2 binary nodes.  The trace kernels are bound by the vector
+// memory front end (address unit and L1 tag rate), not by arithmetic, which is
+// why trading bytes for decode arithmetic pays.
+//
+// Child planes are decoded in ray space: t = byte * (scale/d) + (origin - o)/d.
+// The boxes are conservative (see DevQWideNode), the hit children are visited
+// nearest first (ties in slot order = left to right) and the others deferred
+// nearest on top.  The triangle arithmetic is that of the binary forms, so hit
+// distances agree with them except where the visit order matters to rounding
+// (two surfaces within an ulp, boxes culled at a face); ids may differ on exact
+// ties.  No visit counters in this form.
 template <bool ANYHIT, class STACK>
 __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneState &s, STACK &st, unsigned min_active,
                                                     unsigned max_steps)
 {
-    const char *__restrict__ wn = reinterpret_cast<const char *>(sc.wnodes);
-    const char *__restrict__ tb = reinterpret_cast<const char *>(sc.tris);
+    const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(sc.wnodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
     RayRegs &r = s.r;
     unsigned cur = s.cur, tri = s.tri, tri_end = s.tri_end;
     unsigned steps = s.steps;
-    // byte offsets of the near / far plane rows of a node for this ray's direction signs
-    const unsigned nox = s.negx ? 48u : 0u, noy = s.negy ? 64u : 16u, noz = s.negz ? 80u : 32u;
-    const unsigned fox = 48u - nox, foy = 80u - noy, foz = 112u - noz;
-    const float inf = __builtin_inff();
 
     while (cur != kDone && (steps < max_steps || tri < tri_end)) {
         steps++;
@@ -665,45 +644,13 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
             tri_end = first + count;
         }
         const bool in_leaf = tri < tri_end;
-        // the first three 16-byte loads are shared by both kinds of item
-        const char *p = in_leaf ? tb + (size_t)tri * 48u : wn + (size_t)cur * 128u;
-        const float4 a0 = *reinterpret_cast<const float4 *>(p + (in_leaf ? 0u : nox));
-        const float4 a1 = *reinterpret_cast<const float4 *>(p + (in_leaf ? 16u : noy));
-        const float4 a2 = *reinterpret_cast<const float4 *>(p + (in_leaf ? 32u : noz));
+        const float4 *p = in_leaf ? tris + (size_t)tri * 3 : wn + (size_t)cur * 4;
+        float4 a0, a1, a2;
+        uint4 ch;
+        load_item(p, __ballot(!in_leaf), a0, a1, a2, ch);
         bool need_pop = false;
         if (!in_leaf) {
-            const float4 f0 = *reinterpret_cast<const float4 *>(p + fox);
-            const float4 f1 = *reinterpret_cast<const float4 *>(p + foy);
-            const float4 f2 = *reinterpret_cast<const float4 *>(p + foz);
-            const uint4 ch = *reinterpret_cast<const uint4 *>(p + 96u);
-            const float rx = r.rd.x, ry = r.rd.y, rz = r.rd.z;
-            const float ox = -s.ordx, oy = -s.ordy, oz = -s.ordz;
-#define RTC_SLAB(c)                                                                                          \
-    fmaxf(fmaxf(fmaxf(__fmaf_rn(a0.c, rx, ox), __fmaf_rn(a1.c, ry, oy)), __fmaf_rn(a2.c, rz, oz)), r.near_t), \
-        fminf(fminf(fminf(__fmaf_rn(f0.c, rx, ox), __fmaf_rn(f1.c, ry, oy)), __fmaf_rn(f2.c, rz, oz)), r.far_t)
-            const float nf0[2] = {RTC_SLAB(x)}, nf1[2] = {RTC_SLAB(y)}, nf2[2] = {RTC_SLAB(z)}, nf3[2] = {RTC_SLAB(w)};
-#undef RTC_SLAB
-            float k0 = nf0[0] <= nf0[1] ? nf0[0] : inf;
-            float k1 = nf1[0] <= nf1[1] ? nf1[0] : inf;
-            float k2 = nf2[0] <= nf2[1] ? nf2[0] : inf;
-            float k3 = nf3[0] <= nf3[1] ? nf3[0] : inf;
-            unsigned c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-            // stable 4-input sorting network on the entry distance
-            RTC_CE(k0, c0, k1, c1);
-            RTC_CE(k2, c2, k3, c3);
-            RTC_CE(k0, c0, k2, c2);
-            RTC_CE(k1, c1, k3, c3);
-            RTC_CE(k1, c1, k2, c2);
-            if (k0 < inf) {
-                cur = c0;
-                const int n = (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
-                if (n == 3) st.store(st.sp, c3);
-                if (n >= 2) st.store(st.sp + n - 2, c2);
-                if (n >= 1) st.store(st.sp + n - 1, c1);
-                st.sp += n;
-            } else {
-                need_pop = true;
-            }
+            need_pop = qwide_step<ANYHIT>(a0, a1, a2, ch, s, st, cur);
         } else {
             const float t = tri_test(a0, a1, make_float2(a2.x, a2.y), r.o, r.d);
             tri++;
@@ -725,6 +672,68 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
     s.cur = cur;
     s.tri = tri;
     s.tri_end = tri_end;
+    s.steps = steps;
+}
+// While-while form on the quantized 4-wide tree (coherent rays): all lanes walk
+// wide nodes until each has reached a leaf or finished, then the leaves are
+// tested; see traverse() for the loop and traverse_wide_steps() for the node.
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, STACK &st, unsigned min_active,
+                                              unsigned max_steps)
+{
+    const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(sc.wnodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+    RayRegs &r = s.r;
+    unsigned cur = s.cur;
+    unsigned steps = s.steps;
+
+    while (cur != kDone && steps < max_steps) {
+        while (!(cur & kLeafBit) && steps < max_steps) {
+            steps++;
+            const float4 *q = wn + (size_t)cur * 4;
+            const float4 a0 = q[0];
+            const float4 a1 = q[1];
+            const float4 a2 = q[2];
+            const uint4 ch = *reinterpret_cast<const uint4 *>(q + 3);
+            if (qwide_step<ANYHIT>(a0, a1, a2, ch, s, st, cur)) cur = st.sp ? st.pop() : kDone;
+        }
+        if ((cur & kLeafBit) && cur != kDone) {
+            steps++;
+            unsigned first, count;
+            if (cur & kBigLeafBit) {
+                const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
+                first = bl.first;
+                count = bl.count;
+            } else {
+                first = (cur >> 3) & (kMaxPackedFirst - 1u);
+                count = (cur & 7u) + 1u;
+            }
+            bool occluded = false;
+            for (unsigned i = 0; i < count; i++) {
+                const size_t base = (size_t)(first + i) * 3;
+                const float4 t0 = tris[base + 0];
+                const float4 t1 = tris[base + 1];
+                const float2 t2 = *reinterpret_cast<const float2 *>(tris + base + 2);
+                const float t = tri_test(t0, t1, t2, r.o, r.d);
+                if (t >= r.near_t && t < r.far_t) {
+                    if (ANYHIT) {
+                        occluded = true;
+                        break;
+                    }
+                    r.far_t = t;
+                    s.hit = __float_as_uint(t2.y);
+                }
+            }
+            if (ANYHIT && occluded) {
+                s.hit = 1u;
+                cur = kDone;
+            } else {
+                cur = st.sp ? st.pop() : kDone;
+            }
+        }
+        if ((unsigned)__popcll(__ballot(true)) < min_active) break;
+    }
+    s.cur = cur;
     s.steps = steps;
 }
 #undef RTC_CE
@@ -751,7 +760,7 @@ struct CoopItem {
     float tnear;
 };
 
-template <bool ANYHIT, bool STATS, bool WIDE, bool SENTINEL, int BLOCK, int LDS_DEPTH>
+template <bool ANYHIT, bool STATS, bool WIDE, int BLOCK, int LDS_DEPTH>
 __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, Stack<BLOCK, LDS_DEPTH> &st, Counters &cnt,
                                          unsigned p, CoopItem *work, unsigned cap)
 {
@@ -778,23 +787,21 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
     {
         unsigned *lds_p = st.lds - (threadIdx.x & 63) + p;            // column of lane p
         unsigned *ovf_p = st.ovf - (size_t)(threadIdx.x & 63) + p;
-        // with SENTINEL entry 0 of the lane's stack is the kDone marker, not work
-        const int skip = SENTINEL ? 1 : 0;
-        for (int e = (int)lane + skip; e < sp_p; e += 64) {
+        for (int e = (int)lane; e < sp_p; e += 64) {
             unsigned ref;
-            if (LDS_DEPTH == kAllLds || e < LDS_DEPTH)
+            if (e < LDS_DEPTH)
                 ref = lds_p[e * BLOCK];
             else
                 ref = ovf_p[(size_t)(e - LDS_DEPTH) * st.ovf_stride];
             // a ray parked by the 4-wide traversal holds wide node indices: continue in
             // the binary node each of them was collapsed from
-            if (WIDE && !(ref & kLeafBit)) ref = sc.wnodes[ref].bin;
-            work[e - skip] = CoopItem{ref, -__builtin_inff()};
+            if (WIDE && !(ref & kLeafBit)) ref = sc.wbin[ref];
+            work[e] = CoopItem{ref, -__builtin_inff()};
         }
-        count = (unsigned)(sp_p - skip);
+        count = (unsigned)sp_p;
         if (lane == 0) {
             unsigned ref = cur_p;
-            if (WIDE && !(ref & kLeafBit)) ref = sc.wnodes[ref].bin;
+            if (WIDE && !(ref & kLeafBit)) ref = sc.wbin[ref];
             work[count] = CoopItem{ref, -__builtin_inff()};
         }
         count += 1;
@@ -928,7 +935,7 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
         }
         s.cur = kDone;
         s.tri = s.tri_end = 0;
-        st.sp = SENTINEL ? 1 : 0;
+        st.sp = 0;
     }
 }
 
@@ -1043,19 +1050,14 @@ template <bool ANYHIT, bool STATS, int MODE, class IO>
 __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel(SceneDev sc, IO io, const unsigned *n_ptr, unsigned n_val,
                                                       TraceLaunch tl)
 {
-    // MODE 3 keeps the whole stack in LDS (the launch sizes the dynamic segment for
-    // the scene's stack bound), the other forms a fixed part plus a global overflow area
-    extern __shared__ unsigned lds_dyn[];
-    __shared__ unsigned lds_static[MODE == 3 ? 1 : kLdsDepth * kBlock];
-    unsigned *lds_stack = MODE == 3 ? lds_dyn : lds_static;
+    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
     const unsigned n = n_ptr ? *n_ptr : n_val;
     const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
-    Stack<kBlock, MODE == 3 ? kAllLds : kLdsDepth> st;
+    Stack<kBlock, kLdsDepth> st;
     st.lds = lds_stack + threadIdx.x;
     st.ovf = tl.ovf + gtid;
     st.ovf_stride = gridDim.x * kBlock;
     st.sp = 0;
-    if (MODE == 3) lds_stack[threadIdx.x] = kDone; // bottom entry: popping it ends the ray
     Counters cnt{0, 0, 0, 0, 0};
     unsigned long long nrays = 0;
 
@@ -1087,8 +1089,8 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
                     ray = tl.perm[idx];
                     if (ray >= n) ray = idx; // never index outside the queue, whatever the permutation holds
                 }
-                lane_begin(s, MODE == 2 ? sc.wroot_ref : sc.root_ref, io.load(ray), ray);
-                st.sp = MODE == 3 ? 1 : 0;
+                lane_begin(s, MODE >= 2 ? sc.wroot_ref : sc.root_ref, io.load(ray), ray);
+                st.sp = 0;
                 if (STATS) {
                     nrays++;
                     cnt.ray_start = cnt.inner + cnt.tris;
@@ -1106,7 +1108,7 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
         if (MODE == 0)
             traverse<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else if (MODE == 3)
-            traverse_vote<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+            traverse_wide<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else if (MODE == 2)
             traverse_wide_steps<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else
@@ -1119,7 +1121,7 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
             CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
             while (parked != 0) {
                 const unsigned p = (unsigned)__ffsll((long long)parked) - 1u;
-                coop_finish<ANYHIT, STATS, MODE == 2, MODE == 3>(sc, s, st, cnt, p, work, tl.coop_cap);
+                coop_finish<ANYHIT, STATS, (MODE >= 2)>(sc, s, st, cnt, p, work, tl.coop_cap);
                 parked &= parked - 1ull;
             }
         }
@@ -1537,9 +1539,6 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *accum, unsign
 // ------------------------------------------------------------------------
 // launchers
 
-constexpr unsigned kMaxStackLds = 64u * 1024u; // per workgroup
-constexpr unsigned kLdsPerCu = 160u * 1024u;
-
 static unsigned trace_grid(unsigned n, unsigned max_blocks)
 {
     unsigned need = (n + kBlock - 1) / kBlock;
@@ -1551,20 +1550,19 @@ template <int MODE, class IO>
 static void launch_trace_mode(bool anyhit, bool stats, const SceneDev &sc, const IO &io, const unsigned *n_ptr,
                               unsigned n_val, unsigned grid, const TraceLaunch &tl, hipStream_t stream)
 {
-    const unsigned smem = MODE == 3 ? tl.lds_entries * kBlock * (unsigned)sizeof(unsigned) : 0u;
     if (anyhit) {
         if (stats)
-            hipLaunchKernelGGL((trace_kernel<true, true, MODE, IO>), dim3(grid), dim3(kBlock), smem, stream, sc, io,
+            hipLaunchKernelGGL((trace_kernel<true, true, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
                                n_ptr, n_val, tl);
         else
-            hipLaunchKernelGGL((trace_kernel<true, false, MODE, IO>), dim3(grid), dim3(kBlock), smem, stream, sc, io,
+            hipLaunchKernelGGL((trace_kernel<true, false, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
                                n_ptr, n_val, tl);
     } else {
         if (stats)
-            hipLaunchKernelGGL((trace_kernel<false, true, MODE, IO>), dim3(grid), dim3(kBlock), smem, stream, sc, io,
+            hipLaunchKernelGGL((trace_kernel<false, true, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
                                n_ptr, n_val, tl);
         else
-            hipLaunchKernelGGL((trace_kernel<false, false, MODE, IO>), dim3(grid), dim3(kBlock), smem, stream, sc, io,
+            hipLaunchKernelGGL((trace_kernel<false, false, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
                                n_ptr, n_val, tl);
     }
 }
@@ -1575,22 +1573,23 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
                          hipStream_t stream)
 {
     const unsigned grid = trace_grid(n_upper, max_blocks);
-    if (tl.mode == 2 && !stats && sc.wnodes) {
-        // 4-wide tree, no visit counters in this form
-        if (anyhit)
-            hipLaunchKernelGGL((trace_kernel<true, false, 2, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io, n_ptr,
-                               n_val, tl);
-        else
-            hipLaunchKernelGGL((trace_kernel<false, false, 2, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io, n_ptr,
-                               n_val, tl);
-    } else if (tl.mode == 3 && tl.lds_entries * kBlock * sizeof(unsigned) <= kMaxStackLds) {
-        // all-LDS stack: the resident blocks per CU follow from its size
-        const unsigned lds_bytes = tl.lds_entries * kBlock * (unsigned)sizeof(unsigned);
-        const unsigned per_cu = (unsigned)trace_blocks_per_cu();
-        const unsigned cus = max_blocks / per_cu;
-        const unsigned fit = kLdsPerCu / lds_bytes;
-        const unsigned g = cus * (fit < per_cu ? fit : per_cu);
-        launch_trace_mode<3>(anyhit, stats, sc, io, n_ptr, n_val, grid < g ? grid : (g ? g : 1u), tl, stream);
+    if (tl.mode >= 2 && !stats && sc.wnodes) {
+        // 4-wide tree, no visit counters in these forms
+        if (tl.mode == 2) {
+            if (anyhit)
+                hipLaunchKernelGGL((trace_kernel<true, false, 2, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                                   n_ptr, n_val, tl);
+            else
+                hipLaunchKernelGGL((trace_kernel<false, false, 2, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                                   n_ptr, n_val, tl);
+        } else {
+            if (anyhit)
+                hipLaunchKernelGGL((trace_kernel<true, false, 3, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                                   n_ptr, n_val, tl);
+            else
+                hipLaunchKernelGGL((trace_kernel<false, false, 3, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                                   n_ptr, n_val, tl);
+        }
     }
     else if (tl.mode == 0)
         launch_trace_mode<0>(anyhit, stats, sc, io, n_ptr, n_val, grid, tl, stream);

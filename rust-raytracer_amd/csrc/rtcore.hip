@@ -107,7 +107,10 @@ struct rt_ctx {
     unsigned min_active[2] = {48, 48}; // [0] closest-hit, [1] any-hit launches
     // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
     // while-while form wins), [1] for deeper launches and the stream entry points
-    unsigned trav_mode[2] = {0, 1};
+    unsigned trav_mode[2] = {3, 2};
+    // the stream entry points are the reference's Bvh::intersect_stream / occluded_stream
+    // boundary and walk the reference's binary tree unless told otherwise
+    unsigned trav_stream = 1;
     // queues are reordered by the Morton code of the ray origin from these depths
     // on (depth of the launch that consumes the queue); 0xFFFFFFFF = never
     unsigned sort_from_depth[2] = {2, 1}; // [0] extend, [1] connect
@@ -126,7 +129,7 @@ struct rt_scene {
     rt_ctx *ctx = nullptr;
     HostBvh host;
     uint32_t num_triangles = 0;
-    DevBuf nodes, wnodes, tris, big, normals;
+    DevBuf nodes, wnodes, wbin, tris, big, normals;
     uint32_t num_wide_nodes = 0;
     uint32_t stack_bound = 0; // entries a lane's traversal stack can need on this scene
     SceneDev dev{};
@@ -157,7 +160,6 @@ static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl)
     // the work stack takes over a lane's whole traversal stack and then needs the
     // headroom coop_finish documents
     tl.coop_steps = (2u * sc->dev.max_depth + 68u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
-    tl.lds_entries = sc->dev.max_depth + 2u; // binary walk: one deferred sibling per level, plus entry 0
 }
 
 static int timed_begin(rt_ctx *ctx, int kind, hipStream_t s, size_t *slot)
@@ -221,6 +223,10 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_TRAVERSAL")) {
         int v = atoi(env);
         if (v >= 0 && v <= 3) ctx->trav_mode[0] = ctx->trav_mode[1] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_TRAVERSAL_STREAM")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= 3) ctx->trav_stream = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
         int v = atoi(env);
@@ -304,6 +310,8 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->coop_steps = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
     } else if (n == "min_active" && in(1, 64)) {
         ctx->min_active[0] = ctx->min_active[1] = (unsigned)value;
+    } else if (n == "traversal_stream" && in(0, 3)) {
+        ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
         ctx->trav_mode[0] = (unsigned)value;
     } else if (n == "traversal_deep" && in(0, 3)) {
@@ -518,8 +526,12 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     uint32_t wide_depth = 0;
     const uint32_t wroot = collapse_wide4(dn.data(), dn.size(), root, wn, &wide_depth);
     sc->num_wide_nodes = (uint32_t)wn.size();
+    std::vector<DevQWideNode> qn;
+    std::vector<uint32_t> wbin;
+    quantize_wide4(wn, qn, wbin);
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
-    if (rc == RT_OK) rc = upload(sc->wnodes, wn.data(), wn.size() * sizeof(DevWideNode));
+    if (rc == RT_OK) rc = upload(sc->wnodes, qn.data(), qn.size() * sizeof(DevQWideNode));
+    if (rc == RT_OK) rc = upload(sc->wbin, wbin.data(), wbin.size() * sizeof(uint32_t));
     if (rc == RT_OK) rc = upload(sc->tris, dt.data(), dt.size() * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
     if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
@@ -550,7 +562,8 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     sc->dev.big_leaves = (const BigLeaf *)sc->big.p;
     sc->dev.normals = (const float *)sc->normals.p;
     sc->dev.root_ref = root;
-    sc->dev.wnodes = (const DevWideNode *)sc->wnodes.p;
+    sc->dev.wnodes = (const DevQWideNode *)sc->wnodes.p;
+    sc->dev.wbin = (const uint32_t *)sc->wbin.p;
     sc->dev.wroot_ref = wroot;
     sc->dev.max_depth = hb.stats.max_depth;
     *out = sc;
@@ -591,8 +604,8 @@ extern "C" int rt_bvh_build_host(const float *positions, uint32_t num_vertices, 
 }
 
 extern "C" int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref,
-                                uint32_t root_count, rt_wide_node *out, uint32_t *num_wide, uint32_t *wide_root_ref,
-                                uint32_t *wide_depth)
+                                uint32_t root_count, rt_wide_node *out, rt_qwide_node *qout, uint32_t *num_wide,
+                                uint32_t *wide_root_ref, uint32_t *wide_depth)
 {
     if ((num_nodes && !nodes) || !num_wide || !wide_root_ref)
         return fail(RT_ERR_INVALID, "rt_bvh_wide_host: NULL argument");
@@ -615,6 +628,13 @@ extern "C" int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, u
         if (wide_depth) *wide_depth = depth;
         static_assert(sizeof(rt_wide_node) == sizeof(DevWideNode), "rt_wide_node is the device layout");
         if (out && !wn.empty()) memcpy(out, wn.data(), wn.size() * sizeof(DevWideNode));
+        if (qout && !wn.empty()) {
+            std::vector<DevQWideNode> qn;
+            std::vector<uint32_t> wbin;
+            quantize_wide4(wn, qn, wbin);
+            static_assert(sizeof(rt_qwide_node) == sizeof(DevQWideNode), "rt_qwide_node is the device layout");
+            memcpy(qout, qn.data(), qn.size() * sizeof(DevQWideNode));
+        }
     } catch (const std::exception &ex) {
         return fail(RT_ERR_NOMEM, "rt_bvh_wide_host: %s", ex.what());
     }
@@ -628,6 +648,7 @@ extern "C" void rt_scene_destroy(rt_scene *sc)
     (void)hipDeviceSynchronize();
     sc->nodes.release();
     sc->wnodes.release();
+    sc->wbin.release();
     sc->tris.release();
     sc->big.release();
     sc->normals.release();
@@ -699,7 +720,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
-                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_mode[1], nullptr, nullptr, 0, 0};
+                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_stream, nullptr, nullptr, 0, 0};
     fill_coop(ctx, sc, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());

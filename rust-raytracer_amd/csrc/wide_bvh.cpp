@@ -1,5 +1,7 @@
 #include "wide_bvh.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <limits>
 
 namespace rtc {
@@ -97,6 +99,59 @@ uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, 
     }
     if (max_wide_depth) *max_wide_depth = deepest;
     return root_index;
+}
+
+void quantize_wide4(const std::vector<DevWideNode> &wide, std::vector<DevQWideNode> &out,
+                    std::vector<uint32_t> &bin)
+{
+    out.resize(wide.size());
+    bin.resize(wide.size());
+    for (size_t w = 0; w < wide.size(); w++) {
+        const DevWideNode &src = wide[w];
+        DevQWideNode &q = out[w];
+        bin[w] = src.bin;
+        int n = 0;
+        while (n < 4 && std::isfinite(src.lo[0][n])) n++;
+        for (int k = 0; k < 3; k++) {
+            double nlo = src.lo[k][0], nhi = src.hi[k][0];
+            for (int i = 1; i < n; i++) {
+                nlo = std::min<double>(nlo, src.lo[k][i]);
+                nhi = std::max<double>(nhi, src.hi[k][i]);
+            }
+            const double ext = nhi - nlo;
+            double margin = std::ldexp(std::max({std::fabs(nlo), std::fabs(nhi), ext}), -18);
+            if (!(margin > 0.0)) margin = std::ldexp(1.0, -100); // a node at the coordinate origin with no extent
+            // origin: a float at or below nlo - margin
+            float origin = (float)(nlo - margin);
+            if ((double)origin > nlo - margin) origin = std::nextafterf(origin, -std::numeric_limits<float>::infinity());
+            // scale: a float with origin + 255 * scale >= nhi + margin
+            float scale = (float)((nhi + margin - (double)origin) / 255.0);
+            while ((double)origin + 255.0 * (double)scale < nhi + margin || !(scale > 0.f))
+                scale = std::nextafterf(scale, std::numeric_limits<float>::infinity());
+            q.origin[k] = origin;
+            q.scale[k] = scale;
+            uint32_t lo_word = 0, hi_word = 0;
+            for (int i = 0; i < 4; i++) {
+                uint32_t bl = 255, bh = 0; // unused slot: near plane beyond far plane on every axis
+                if (i < n) {
+                    const double lo = (double)src.lo[k][i] - margin, hi = (double)src.hi[k][i] + margin;
+                    double fl = std::floor((lo - (double)origin) / (double)scale);
+                    fl = std::min(255.0, std::max(0.0, fl));
+                    while (fl > 0.0 && (double)origin + fl * (double)scale > lo + 0.5 * margin) fl -= 1.0;
+                    double ch = std::ceil((hi - (double)origin) / (double)scale);
+                    ch = std::min(255.0, std::max(0.0, ch));
+                    while (ch < 255.0 && (double)origin + ch * (double)scale < hi - 0.5 * margin) ch += 1.0;
+                    bl = (uint32_t)fl;
+                    bh = (uint32_t)ch;
+                }
+                lo_word |= bl << (8 * i);
+                hi_word |= bh << (8 * i);
+            }
+            q.lo[k] = lo_word;
+            q.hi[k] = hi_word;
+        }
+        for (int i = 0; i < 4; i++) q.child[i] = src.child[i];
+    }
 }
 
 } // namespace rtc

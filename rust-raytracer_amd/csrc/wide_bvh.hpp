@@ -23,4 +23,15 @@ namespace rtc {
 uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, std::vector<DevWideNode> &out,
                         uint32_t *max_wide_depth);
 
+// Quantizes the child boxes of `wide` onto the 8-bit grid of DevQWideNode.
+// Per node and axis: origin is placed `margin` below the lowest child plane and
+// scale makes byte 255 reach `margin` above the highest, with
+//     margin = 2^-18 * max(|lowest|, |highest|, extent)
+// (several hundred times the rounding error of the traversal's
+// fma(byte, scale/d, (origin - o)/d) against the exact plane); lower planes are
+// rounded down and upper planes up so that the decoded box, evaluated in double
+// precision, contains the exact one enlarged by half the margin.
+void quantize_wide4(const std::vector<DevWideNode> &wide, std::vector<DevQWideNode> &out,
+                    std::vector<uint32_t> &bin);
+
 } // namespace rtc

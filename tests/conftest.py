@@ -35,12 +35,17 @@ def scenes():
 
 @pytest.fixture(scope="session")
 def ctx(rt):
-    """Context with the cooperative straggler path off: a ray finished by its
-    whole wave keeps its hit distance but not its visit counters, and these
-    tests compare counters with the oracle exactly.  tests/test_gpu_coop.py
-    covers that path."""
+    """Context in its exact configuration: the reference's binary tree in the
+    reference's visit order (traversal forms 0 and 1) and the cooperative
+    straggler path off (a ray finished by its whole wave keeps its hit distance
+    but not its visit counters).  These tests compare distances, ids and
+    counters with the oracle exactly.  tests/test_gpu_coop.py and
+    tests/test_gpu_wide.py cover the other forms, ctx_default the defaults."""
     c = rt.Context(0)
     c.set_option("coop_steps", 0)
+    c.set_option("traversal_depth0", 0)
+    c.set_option("traversal_deep", 1)
+    c.set_option("traversal_stream", 1)
     yield c
     c.close()
 

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 def test_coop_trace_parity(O, rt, ctx_default, scenes, steps, mode):
     ctx = ctx_default
     ctx.set_option("coop_steps", steps)
-    ctx.set_option("traversal_deep", mode)
+    ctx.set_option("traversal_stream", mode)
     try:
         for name, kw in (("test-mesh", {"n_tris": 20000, "seed": 3}), ("sponza-class", {}), ("cornell-class", {})):
             sc = scenes.load(name, **kw)
@@ -50,7 +50,7 @@ def test_coop_trace_parity(O, rt, ctx_default, scenes, steps, mode):
             Sg.close()
     finally:
         ctx.set_option("coop_steps", 512)
-        ctx.set_option("traversal_deep", 1)
+        ctx.set_option("traversal_stream", 1)
 
 
 def test_coop_render_parity(O, rt, ctx_default, scenes):

@@ -31,12 +31,38 @@ def binary_leaves(nodes, root):
     return out
 
 
+def check_quantized(wide, qwide):
+    """Every decoded box (in double precision) contains the exact child box, is not looser than
+    two grid steps plus the builder's margin per side, and unused slots decode to near > far on every axis."""
+    assert len(wide) == len(qwide)
+    for w, q in zip(wide, qwide):
+        assert np.array_equal(w["child"], q["child"])
+        origin = q["origin"].astype(np.float64)
+        scale = q["scale"].astype(np.float64)
+        assert (scale > 0).all()
+        used = [i for i in range(4) if np.isfinite(w["lo"][0][i])]
+        nlo = w["lo"][:, used].astype(np.float64).min(axis=1)
+        nhi = w["hi"][:, used].astype(np.float64).max(axis=1)
+        big = np.maximum(np.maximum(np.abs(nlo), np.abs(nhi)), nhi - nlo)
+        for i in range(4):
+            lo_b = np.array([(int(q["lo"][k]) >> (8 * i)) & 0xFF for k in range(3)], dtype=np.float64)
+            hi_b = np.array([(int(q["hi"][k]) >> (8 * i)) & 0xFF for k in range(3)], dtype=np.float64)
+            if not np.isfinite(w["lo"][0][i]):
+                assert (lo_b == 255).all() and (hi_b == 0).all()
+                continue
+            dlo, dhi = origin + lo_b * scale, origin + hi_b * scale
+            elo, ehi = w["lo"][:, i].astype(np.float64), w["hi"][:, i].astype(np.float64)
+            assert (dlo < elo).all() and (dhi > ehi).all()           # strictly outside: the margin
+            slack = 2.0 * scale + np.ldexp(big, -17)               # two grid steps plus twice the margin
+            assert (elo - dlo <= slack).all() and (dhi - ehi <= slack).all()
+
+
 @pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 3000, "seed": 4}),
                                      ("test-mesh", {"n_tris": 9, "seed": 1}), ("test-mesh", {"n_tris": 5, "seed": 2})])
 def test_wide_collapse_invariants(rt, scenes, name, kw):
     sc = scenes.load(name, **kw)
     nodes, order, info, stats = rt.build_bvh_host(sc.positions, sc.indices)
-    wide, wroot, wdepth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
+    wide, qwide, wroot, wdepth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
     if info["root_ref"] & LEAF:
         assert len(wide) == 0 and wroot == pack(info["root_ref"], info["root_count"])
         return
@@ -81,6 +107,7 @@ def test_wide_collapse_invariants(rt, scenes, name, kw):
             assert all(int(node["child"][i]) & LEAF for i in used)
 
     walk(0)
+    check_quantized(wide, qwide)
     assert int(wide[0]["bin"]) == info["root_ref"]
     assert len(seen_inner) == len(wide) - 1
     assert leaves == binary_leaves(nodes, info["root_ref"])
