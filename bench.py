@@ -34,6 +34,21 @@ WORKLOADS = {
     "san-miguel-class": dict(scene="san-miguel-class", kw={}, bounces=2),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
+# vector L1: 64 B per clock per CU x 256 CUs x 2.4 GHz -- the unit the trace kernels saturate
+L1_PEAK_GBS = 64.0 * 256 * 2.4
+
+
+def measured_counters(workload):
+    """Per-launch hardware counters of this workload's trace kernels from the newest committed
+    rocprofv3 --pmc summary (profiles/rNN_x_pmc_<workload>.json, scripts/gpu_profile_round.sh):
+    counters cannot be read from inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        return json.load(fh), os.path.relpath(files[-1], ROOT)
+
 
 
 def extend_bytes_per_ray(st):
@@ -185,6 +200,11 @@ def main():
         con_rays_per_launch = con_rays / max(1, launches["connect"])
         con_ach = b_con * con_rays_per_launch / (con_avg_ms * 1e-3) / 1e9 if con_avg_ms > 0 else 0.0
         img = total_accum.cpu().numpy()
+        pmc, pmc_file = measured_counters(args.workload)
+        pmc_ext = (pmc or {}).get("extend", {})
+        traffic = None
+        if "hbm_read_bytes_per_launch" in pmc_ext:
+            traffic = pmc_ext["hbm_read_bytes_per_launch"] + pmc_ext.get("hbm_write_bytes_per_launch", 0.0)
         out = {
             "metric": "Mrays/s (primary+secondary+shadow rays, whole job)",
             "value": round(value, 2),
@@ -216,7 +236,16 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": pmc_file,
+                "algorithmic_bytes_per_launch": round(b_ext * ext_rays_per_launch, 0),
+                # the working set is cache resident: the unit these kernels saturate is the vector L1
+                "l1_peak": round(L1_PEAK_GBS, 1),
+                "l1_frac": round(achieved / L1_PEAK_GBS, 4),
+                "counters": {k: round(v, 4) for k, v in pmc_ext.items()
+                             if k in ("l1_cache_busy", "vector_memory_address_unit_busy",
+                                      "valu_issue_busy_at_2_cycles", "active_lanes_per_valu_instruction",
+                                      "l1_hit_rate", "l2_hit_rate")},
                 "bytes_per_ray": round(b_ext, 1),
                 "rays_per_launch": int(ext_rays_per_launch),
                 "avg_launch_ms": round(ext_avg_ms, 4),
