@@ -36,6 +36,7 @@ struct TraceLaunch {
                          // 2 = one item per iteration on the quantized 4-wide tree, 3 = while-while loop on it
                          // (no visit counters in 2 and 3)
     const unsigned *perm; // optional: process ray perm[i] at position i (queue sorted by key), or null
+    unsigned perm_n;      // perm covers (and permutes) queue entries 0..perm_n-1
     // stragglers: a ray that has used coop_steps loop iterations is finished by its
     // whole wave on a wave-private work stack of coop_cap 8-byte entries (coop + wave*cap)
     void *coop;

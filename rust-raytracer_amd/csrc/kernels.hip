@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
             const unsigned idx = begin + base + rank;
             if (!s.have_ray && begin + base < end && idx < end) {
                 unsigned ray = idx;
-                if (tl.perm) {
+                if (tl.perm && idx < tl.perm_n) { // the first perm_n queue entries are ordered, the rest are not
                     ray = tl.perm[idx];
                     if (ray >= n) ray = idx; // never index outside the queue, whatever the permutation holds
                 }

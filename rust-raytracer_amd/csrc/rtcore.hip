@@ -92,6 +92,8 @@ struct Workspace {
 
 } // namespace
 
+constexpr uint32_t kMaxQueueCounters = 1024; // queue-length words of one pass kept for the next pass's sort sizes
+
 struct rt_ctx {
     int device = 0;
     int num_cus = 0;
@@ -116,6 +118,14 @@ struct rt_ctx {
     unsigned sort_from_depth[2] = {2, 1}; // [0] extend, [1] connect
     unsigned sort_bits = 21;              // high bits of the 30-bit key that are sorted
     Workspace ws;
+    // Queue lengths of the last finished render pass, read back asynchronously: the next pass
+    // sorts only that many entries (+ slack) of each queue instead of the whole allocation.
+    uint32_t *h_counts = nullptr; // pinned
+    hipEvent_t counts_ready = nullptr;
+    bool counts_pending = false;
+    std::vector<uint32_t> est_counts; // [0..nb] ray queues, then [0..nb-1] shadow queues
+    uint64_t est_key[3] = {0, 0, 0};  // plan the estimate belongs to: scene, slots, depths
+    uint64_t pending_key[3] = {0, 0, 0};
     uint64_t max_paths = 1ull << 24;
     DevBuf io_a, io_b; // staging for the host-buffer entry points
     std::vector<TimedLaunch> pool;
@@ -259,6 +269,10 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (rc == RT_OK)
         rc = ctx->coop.ensure((size_t)ctx->max_blocks * (RTC_TRACE_BLOCK / 64) * ctx->coop_cap * 8);
     if (rc == RT_OK) rc = ensure_overflow(ctx, 0);
+    if (rc == RT_OK && hipHostMalloc((void **)&ctx->h_counts, kMaxQueueCounters * sizeof(uint32_t)) != hipSuccess)
+        rc = fail(RT_ERR_NOMEM, "rt_ctx_create: pinned host allocation failed");
+    if (rc == RT_OK && hipEventCreateWithFlags(&ctx->counts_ready, hipEventDisableTiming) != hipSuccess)
+        rc = fail(RT_ERR_HIP, "rt_ctx_create: hipEventCreate failed");
     if (rc != RT_OK) {
         rt_ctx_destroy(ctx);
         return rc;
@@ -276,6 +290,8 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->counts_ready) (void)hipEventDestroy(ctx->counts_ready);
     ctx->ovf.release();
     ctx->dstats.release();
     ctx->fetch.release();
@@ -720,7 +736,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
-                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_stream, nullptr, nullptr, 0, 0};
+                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_stream, nullptr, 0, nullptr, 0, 0};
     fill_coop(ctx, sc, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
@@ -978,6 +994,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
     uint32_t *counters = (uint32_t *)w.counters.p;
     unsigned *ovf = (unsigned *)ctx->ovf.p;
 
+    const uint64_t plan_key[3] = {(uint64_t)(uintptr_t)sc, slots, nb};
     for (uint32_t tile0 = 0; tile0 < my_tiles; tile0 += tiles_per_pass) {
         const uint32_t tcount = std::min(tiles_per_pass, my_tiles - tile0);
         for (uint32_t s0 = 0; s0 < params->samples; s0 += k) {
@@ -996,6 +1013,20 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             ps.num_slots = tcount * ts2 * k;
             ps.seed_key = seed_key;
 
+            // queue lengths of the previous pass, if its read-back has landed (never waited for)
+            if (ctx->counts_pending && hipEventQuery(ctx->counts_ready) == hipSuccess) {
+                ctx->est_counts.assign(ctx->h_counts, ctx->h_counts + 2 * (size_t)ctx->pending_key[2] + 1);
+                memcpy(ctx->est_key, ctx->pending_key, sizeof ctx->est_key);
+                ctx->counts_pending = false;
+            }
+            const bool have_est = !ctx->est_counts.empty() && ctx->est_counts.size() == 2 * nb + 1 &&
+                                  memcmp(ctx->est_key, plan_key, sizeof plan_key) == 0;
+            // entries of a queue worth sorting: last pass's length plus 2 % and a block, all if unknown
+            auto sort_len = [&](uint32_t index) -> uint32_t {
+                if (!have_est) return ps.num_slots;
+                uint64_t e = (uint64_t)ctx->est_counts[index] + ctx->est_counts[index] / 50u + 4096u;
+                return (uint32_t)std::min<uint64_t>(e, ps.num_slots);
+            };
             HIP_TRY(hipMemsetAsync(counters, 0, (size_t)ncounters * sizeof(uint32_t), s));
             uint32_t *n_ray = counters;          // [0..nb]
             uint32_t *n_sh = counters + nb + 1;  // [0..nb-1]
@@ -1003,6 +1034,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             int cur = 0;
             size_t slot;
             const unsigned *perm_extend = nullptr; // order of the ray queue about to be extended
+            unsigned perm_extend_n = 0;
             rc = timed_begin(ctx, 2, s, &slot);
             if (rc != RT_OK) return rc;
             launch_generate(cam, ps, (QRay *)w.rays[cur].p, (PathInfo *)w.infos[cur].p, &n_ray[0], rad_r, rad_g,
@@ -1013,7 +1045,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 0, s, &slot);
                 if (rc != RT_OK) return rc;
                 TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0],
-                                ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, nullptr, 0, 0};
+                                ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, perm_extend_n, nullptr, 0, 0};
                 fill_coop(ctx, sc, tle);
                 launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
                               ps.num_slots, tle, ctx->max_blocks, s);
@@ -1049,29 +1081,38 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 a.bounce_keys = sort_bounce ? (uint32_t *)w.keys[0].p : nullptr;
                 rc = timed_begin(ctx, 2, s, &slot);
                 if (rc != RT_OK) return rc;
-                // unused queue tail keeps the largest key so that it sorts behind every ray
-                if (sort_shadow) HIP_TRY(hipMemsetAsync(w.keys[1].p, 0xFF, (size_t)ps.num_slots * sizeof(uint32_t), s));
-                if (sort_bounce) HIP_TRY(hipMemsetAsync(w.keys[0].p, 0xFF, (size_t)ps.num_slots * sizeof(uint32_t), s));
+                // the shadow queue of depth b has counter index nb+1+b, the bounce queue b+1
+                const uint32_t m_shadow = sort_shadow ? sort_len(nb + 1 + b) : 0;
+                const uint32_t m_bounce = sort_bounce ? sort_len(b + 1) : 0;
+                // unused entries keep the largest key so that they sort behind every ray
+                if (sort_shadow) HIP_TRY(hipMemsetAsync(w.keys[1].p, 0xFF, (size_t)m_shadow * sizeof(uint32_t), s));
+                if (sort_bounce) HIP_TRY(hipMemsetAsync(w.keys[0].p, 0xFF, (size_t)m_bounce * sizeof(uint32_t), s));
                 launch_shade(a, ps.num_slots, s);
                 const unsigned *perm_connect = nullptr;
+                unsigned perm_connect_n = 0;
                 if (sort_shadow || sort_bounce) {
-                    size_t tb = sort_temp_bytes(ps.num_slots, 30u - ctx->sort_bits, 32u);
+                    size_t tb = sort_temp_bytes(std::max(m_shadow, m_bounce), 30u - ctx->sort_bits, 32u);
                     if (tb == 0) return fail(RT_ERR_HIP, "radix sort temporary-storage query failed");
+                    tb = std::max(tb, sort_temp_bytes(std::min(m_shadow ? m_shadow : m_bounce, m_bounce ? m_bounce : m_shadow),
+                                                      30u - ctx->sort_bits, 32u));
                     rc = w.sort_temp.ensure(tb);
                     if (rc != RT_OK) return rc;
                 }
                 if (sort_shadow) {
                     HIP_TRY(sort_indices_by_key(w.sort_temp.p, w.sort_temp.bytes, (const unsigned *)w.keys[1].p,
-                                                (unsigned *)w.keys_sorted.p, (unsigned *)w.perm[1].p, ps.num_slots,
+                                                (unsigned *)w.keys_sorted.p, (unsigned *)w.perm[1].p, m_shadow,
                                                 30u - ctx->sort_bits, 32u, s));
                     perm_connect = (const unsigned *)w.perm[1].p;
+                    perm_connect_n = m_shadow;
                 }
                 perm_extend = nullptr;
+                perm_extend_n = 0;
                 if (sort_bounce) {
                     HIP_TRY(sort_indices_by_key(w.sort_temp.p, w.sort_temp.bytes, (const unsigned *)w.keys[0].p,
-                                                (unsigned *)w.keys_sorted.p, (unsigned *)w.perm[0].p, ps.num_slots,
+                                                (unsigned *)w.keys_sorted.p, (unsigned *)w.perm[0].p, m_bounce,
                                                 30u - ctx->sort_bits, 32u, s));
                     perm_extend = (const unsigned *)w.perm[0].p;
+                    perm_extend_n = m_bounce;
                 }
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
@@ -1079,7 +1120,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
                 TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1],
-                                ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, nullptr, 0, 0};
+                                ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, perm_connect_n, nullptr, 0, 0};
                 fill_coop(ctx, sc, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
                                &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
@@ -1093,6 +1134,13 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             launch_accumulate(ps, rad_r, rad_g, rad_b, d_accum, s);
             rc = timed_end(ctx, slot, s);
             if (rc != RT_OK) return rc;
+            if (sort_any && !ctx->counts_pending && 2 * nb + 1 <= kMaxQueueCounters) {
+                HIP_TRY(hipMemcpyAsync(ctx->h_counts, counters, (size_t)(2 * nb + 1) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipEventRecord(ctx->counts_ready, s));
+                ctx->counts_pending = true;
+                memcpy(ctx->pending_key, plan_key, sizeof plan_key);
+            }
             HIP_TRY(hipGetLastError());
         }
     }
