@@ -118,10 +118,16 @@ struct SceneDev {
     const float *normals; // float4 per mesh triangle (xyz, 0)
     uint32_t root_ref;
     uint32_t max_depth;
-    // 4-wide quantized form of the same tree (optional fast traversal), null when absent
+    // 4-wide quantized form of the same tree (optional fast traversal), null when absent.
+    // It is built over the refined binary tree `xnodes` (the reference's tree with its larger
+    // leaves split further) and that tree's leaf order `xtris`; `nodes`/`tris` above stay the
+    // reference's tree for the exact forms.
     const DevQWideNode *wnodes;
-    const uint32_t *wbin; // per wide node: the binary node it was collapsed from
+    const uint32_t *wbin; // per wide node: the node of `xnodes` it was collapsed from
+    const DevNode *xnodes;
+    const DevTri *xtris;
     uint32_t wroot_ref;
+    uint32_t xmax_depth;
 };
 
 // Counters of src/trace_stats.rs:4-12 as kept on the device.

@@ -623,7 +623,7 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
                                                     unsigned max_steps)
 {
     const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(sc.wnodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.xtris);
     RayRegs &r = s.r;
     unsigned cur = s.cur, tri = s.tri, tri_end = s.tri_end;
     unsigned steps = s.steps;
@@ -682,7 +682,7 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
                                               unsigned max_steps)
 {
     const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(sc.wnodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.xtris);
     RayRegs &r = s.r;
     unsigned cur = s.cur;
     unsigned steps = s.steps;
@@ -764,8 +764,9 @@ template <bool ANYHIT, bool STATS, bool WIDE, int BLOCK, int LDS_DEPTH>
 __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, Stack<BLOCK, LDS_DEPTH> &st, Counters &cnt,
                                          unsigned p, CoopItem *work, unsigned cap)
 {
-    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
+    // a ray parked by a wide form continues in the refined binary tree the wide tree was made from
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(WIDE ? sc.xnodes : sc.nodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(WIDE ? sc.xtris : sc.tris);
     const unsigned lane = lane_id();
 
     // the ray of lane p, in every lane
@@ -813,7 +814,7 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
     // count <= lim = cap - reserve; at the limit one entry is popped per iteration,
     // which is a plain depth-first walk and grows the stack by at most the tree depth
     // (reserve = max_depth + 2).  The host guarantees cap > reserve + 64 + max_depth.
-    const unsigned lim = cap - (sc.max_depth + 2u);
+    const unsigned lim = cap - ((WIDE ? sc.xmax_depth : sc.max_depth) + 2u);
     bool found = false; // any-hit result (wave-uniform)
     while (count != 0 && !(ANYHIT && found)) {
         unsigned m = count < 64u ? count : 64u;

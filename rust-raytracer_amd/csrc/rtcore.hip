@@ -139,7 +139,7 @@ struct rt_scene {
     rt_ctx *ctx = nullptr;
     HostBvh host;
     uint32_t num_triangles = 0;
-    DevBuf nodes, wnodes, wbin, tris, big, normals;
+    DevBuf nodes, wnodes, wbin, xnodes, xtris, tris, big, normals;
     uint32_t num_wide_nodes = 0;
     uint32_t stack_bound = 0; // entries a lane's traversal stack can need on this scene
     SceneDev dev{};
@@ -169,7 +169,7 @@ static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl)
     tl.coop_cap = ctx->coop_cap;
     // the work stack takes over a lane's whole traversal stack and then needs the
     // headroom coop_finish documents
-    tl.coop_steps = (2u * sc->dev.max_depth + 68u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
+    tl.coop_steps = (2u * sc->dev.xmax_depth + 68u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
 }
 
 static int timed_begin(rt_ctx *ctx, int kind, hipStream_t s, size_t *slot)
@@ -508,21 +508,37 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     std::vector<BigLeaf> big;
     std::vector<DevNode> dn;
     const uint32_t root = make_dev_nodes(hb.nodes.data(), hb.nodes.size(), hb.root_ref, hb.root_count, dn, big);
-    std::vector<DevTri> dt(num_triangles);
-    for (uint32_t slot = 0; slot < num_triangles; slot++) {
-        uint32_t t = hb.order[slot];
-        const float *a = positions + 3 * (size_t)indices[3 * (size_t)t + 0];
-        const float *b = positions + 3 * (size_t)indices[3 * (size_t)t + 1];
-        const float *c = positions + 3 * (size_t)indices[3 * (size_t)t + 2];
-        DevTri &d = dt[slot];
-        for (int k = 0; k < 3; k++) { // src/triangle_opt.rs:72-81
-            d.v0[k] = a[k];
-            d.e1[k] = b[k] - a[k];
-            d.e2[k] = c[k] - a[k];
+    auto make_tris = [&](const std::vector<uint32_t> &order, std::vector<DevTri> &dt) {
+        dt.resize(num_triangles);
+        for (uint32_t slot = 0; slot < num_triangles; slot++) {
+            uint32_t t = order[slot];
+            const float *a = positions + 3 * (size_t)indices[3 * (size_t)t + 0];
+            const float *b = positions + 3 * (size_t)indices[3 * (size_t)t + 1];
+            const float *c = positions + 3 * (size_t)indices[3 * (size_t)t + 2];
+            DevTri &d = dt[slot];
+            for (int k = 0; k < 3; k++) { // src/triangle_opt.rs:72-81
+                d.v0[k] = a[k];
+                d.e1[k] = b[k] - a[k];
+                d.e2[k] = c[k] - a[k];
+            }
+            d.id = t;
+            d.pad[0] = d.pad[1] = 0;
         }
-        d.id = t;
-        d.pad[0] = d.pad[1] = 0;
+    };
+    std::vector<DevTri> dt;
+    make_tris(hb.order, dt);
+    // the wide tree is built over a copy of the tree whose larger leaves are split further
+    unsigned leaf_tris = 3;
+    if (const char *env = getenv("RTCORE_WIDE_LEAF_TRIS")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 8) leaf_tris = (unsigned)v;
     }
+    std::vector<DevNode> xdn;
+    std::vector<uint32_t> xorder;
+    uint32_t xroot = root;
+    const uint32_t extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, xdn, xroot, xorder);
+    std::vector<DevTri> xdt;
+    make_tris(xorder, xdt);
     std::vector<float> n4((size_t)num_triangles * 4);
     for (uint32_t t = 0; t < num_triangles; t++) {
         n4[4 * (size_t)t + 0] = geom_normals[3 * (size_t)t + 0];
@@ -540,7 +556,7 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     };
     std::vector<DevWideNode> wn;
     uint32_t wide_depth = 0;
-    const uint32_t wroot = collapse_wide4(dn.data(), dn.size(), root, wn, &wide_depth);
+    const uint32_t wroot = collapse_wide4(xdn.data(), xdn.size(), xroot, wn, &wide_depth);
     sc->num_wide_nodes = (uint32_t)wn.size();
     std::vector<DevQWideNode> qn;
     std::vector<uint32_t> wbin;
@@ -548,12 +564,14 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
     if (rc == RT_OK) rc = upload(sc->wnodes, qn.data(), qn.size() * sizeof(DevQWideNode));
     if (rc == RT_OK) rc = upload(sc->wbin, wbin.data(), wbin.size() * sizeof(uint32_t));
+    if (rc == RT_OK) rc = upload(sc->xnodes, xdn.data(), xdn.size() * sizeof(DevNode));
+    if (rc == RT_OK) rc = upload(sc->xtris, xdt.data(), xdt.size() * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->tris, dt.data(), dt.size() * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
     if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
     // Deepest traversal stack of a lane.  Binary walk: one deferred sibling per level.
     // Wide walk: up to three deferred children per wide level.
-    sc->stack_bound = std::max(hb.stats.max_depth, 3u * wide_depth) + 1u;
+    sc->stack_bound = std::max(hb.stats.max_depth + extra_depth, 3u * wide_depth) + 1u;
     if (rc == RT_OK) rc = ensure_overflow(ctx, sc->stack_bound);
     if (rc != RT_OK) {
         rt_scene_destroy(sc);
@@ -580,6 +598,9 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     sc->dev.root_ref = root;
     sc->dev.wnodes = (const DevQWideNode *)sc->wnodes.p;
     sc->dev.wbin = (const uint32_t *)sc->wbin.p;
+    sc->dev.xnodes = (const DevNode *)sc->xnodes.p;
+    sc->dev.xtris = (const DevTri *)sc->xtris.p;
+    sc->dev.xmax_depth = hb.stats.max_depth + extra_depth;
     sc->dev.wroot_ref = wroot;
     sc->dev.max_depth = hb.stats.max_depth;
     *out = sc;
@@ -665,6 +686,8 @@ extern "C" void rt_scene_destroy(rt_scene *sc)
     sc->nodes.release();
     sc->wnodes.release();
     sc->wbin.release();
+    sc->xnodes.release();
+    sc->xtris.release();
     sc->tris.release();
     sc->big.release();
     sc->normals.release();

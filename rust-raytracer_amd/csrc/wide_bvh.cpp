@@ -101,6 +101,155 @@ uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, 
     return root_index;
 }
 
+namespace {
+
+struct Box3 {
+    float lo[3], hi[3];
+    void reset()
+    {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::numeric_limits<float>::infinity();
+            hi[k] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const Box3 &o)
+    {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], o.lo[k]);
+            hi[k] = std::max(hi[k], o.hi[k]);
+        }
+    }
+    float area() const
+    {
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return 2.f * (x * y + x * z + y * z);
+    }
+};
+
+struct Refiner {
+    const float *positions;
+    const uint32_t *indices;
+    unsigned max_tris;
+    std::vector<DevNode> *xn;
+    std::vector<uint32_t> *xorder;
+    uint32_t deepest = 0;
+
+    Box3 tri_box(uint32_t t) const
+    {
+        Box3 b;
+        b.reset();
+        for (int v = 0; v < 3; v++) {
+            const float *p = positions + 3 * (size_t)indices[3 * (size_t)t + v];
+            for (int k = 0; k < 3; k++) {
+                b.lo[k] = std::min(b.lo[k], p[k]);
+                b.hi[k] = std::max(b.hi[k], p[k]);
+            }
+        }
+        return b;
+    }
+    float centroid(uint32_t t, int k) const
+    {
+        const float *a = positions + 3 * (size_t)indices[3 * (size_t)t + 0];
+        const float *b = positions + 3 * (size_t)indices[3 * (size_t)t + 1];
+        const float *c = positions + 3 * (size_t)indices[3 * (size_t)t + 2];
+        return (a[k] + b[k] + c[k]) / 3.f;
+    }
+    static uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | (first << 3) | (count - 1u); }
+
+    // slots [first, first + n) of xorder, n <= 8; returns the reference that replaces the leaf
+    uint32_t split(uint32_t first, uint32_t n, uint32_t depth)
+    {
+        if (n <= max_tris) return leaf_ref(first, n);
+        uint32_t *slot = xorder->data() + first;
+        float clo[3], chi[3];
+        for (int k = 0; k < 3; k++) {
+            clo[k] = std::numeric_limits<float>::infinity();
+            chi[k] = -clo[k];
+        }
+        for (uint32_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                const float c = centroid(slot[i], k);
+                clo[k] = std::min(clo[k], c);
+                chi[k] = std::max(chi[k], c);
+            }
+        int axis = 0;
+        for (int k = 1; k < 3; k++)
+            if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+        if (!(chi[axis] - clo[axis] > 0.f)) return leaf_ref(first, n); // nothing to order by
+        std::stable_sort(slot, slot + n, [&](uint32_t a, uint32_t b) {
+            const float ca = centroid(a, axis), cb = centroid(b, axis);
+            return ca < cb || (ca == cb && a < b);
+        });
+        Box3 suffix[9];
+        suffix[n].reset();
+        for (uint32_t i = n; i-- > 0;) {
+            suffix[i] = suffix[i + 1];
+            suffix[i].grow(tri_box(slot[i]));
+        }
+        Box3 prefix;
+        prefix.reset();
+        uint32_t best_k = 1;
+        float best_cost = std::numeric_limits<float>::infinity();
+        Box3 best_a = prefix;
+        for (uint32_t k = 1; k < n; k++) {
+            prefix.grow(tri_box(slot[k - 1]));
+            const float cost = prefix.area() * (float)k + suffix[k].area() * (float)(n - k);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_k = k;
+                best_a = prefix;
+            }
+        }
+        const Box3 box_a = best_a, box_b = suffix[best_k];
+        const uint32_t self = (uint32_t)xn->size();
+        xn->emplace_back();
+        deepest = std::max(deepest, depth);
+        const uint32_t l = split(first, best_k, depth + 1);
+        const uint32_t r = split(first + best_k, n - best_k, depth + 1);
+        DevNode &d = (*xn)[self];
+        float *b[3] = {d.bx, d.by, d.bz};
+        for (int k = 0; k < 3; k++) {
+            b[k][0] = box_a.lo[k];
+            b[k][1] = box_b.lo[k];
+            b[k][2] = box_a.hi[k];
+            b[k][3] = box_b.hi[k];
+        }
+        d.left = l;
+        d.right = r;
+        d.pad0 = d.pad1 = 0;
+        return self;
+    }
+    uint32_t refine_ref(uint32_t ref)
+    {
+        if (!(ref & kLeafBit) || (ref & kBigLeafBit)) return ref;
+        const uint32_t first = (ref >> 3) & (kMaxPackedFirst - 1u), count = (ref & 7u) + 1u;
+        return split(first, count, 1);
+    }
+};
+
+} // namespace
+
+uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const float *positions,
+                       const uint32_t *indices, const std::vector<uint32_t> &order, unsigned max_tris,
+                       std::vector<DevNode> &xn, uint32_t &xroot, std::vector<uint32_t> &xorder)
+{
+    xn = bn;
+    xorder = order;
+    xroot = root_ref;
+    if (max_tris < 1 || max_tris >= 8) return 0;
+    Refiner rf{positions, indices, max_tris, &xn, &xorder};
+    const size_t n = bn.size();
+    xn.reserve(n + n / 2 + 8);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t l = rf.refine_ref(bn[i].left);
+        const uint32_t r = rf.refine_ref(bn[i].right);
+        xn[i].left = l;
+        xn[i].right = r;
+    }
+    xroot = rf.refine_ref(root_ref);
+    return rf.deepest;
+}
+
 void quantize_wide4(const std::vector<DevWideNode> &wide, std::vector<DevQWideNode> &out,
                     std::vector<uint32_t> &bin)
 {

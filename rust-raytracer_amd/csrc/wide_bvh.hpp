@@ -23,6 +23,23 @@ namespace rtc {
 uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, std::vector<DevWideNode> &out,
                         uint32_t *max_wide_depth);
 
+// Finer leaves for the wide tree.  The reference stops splitting at 8 triangles
+// (src/bvh/build.rs:80-81), a leaf size chosen for 8-wide CPU SIMD; a GPU lane
+// tests triangles one at a time and every test costs three 16-byte gathers.
+// Every packed leaf of more than `max_tris` triangles is replaced by a small
+// binary subtree over its own triangles: triangles are ordered by centroid
+// along the leaf's largest centroid-extent axis and cut where
+// area(A)*|A| + area(B)*|B| is smallest, recursively; child boxes are the exact
+// unions of the triangles' vertex bounds.  The result is a copy of the binary
+// tree (`xn`: the original nodes at their original indices, new nodes appended)
+// and of the leaf order (`xorder`: a permutation of `order` that only moves
+// triangles inside their reference leaf).  Leaves of the zero-centroid-extent
+// rule (src/bvh/build.rs:93-101) are left alone.  Returns the number of levels
+// the deepest new subtree adds.
+uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const float *positions,
+                       const uint32_t *indices, const std::vector<uint32_t> &order, unsigned max_tris,
+                       std::vector<DevNode> &xn, uint32_t &xroot, std::vector<uint32_t> &xorder);
+
 // Quantizes the child boxes of `wide` onto the 8-bit grid of DevQWideNode.
 // Per node and axis: origin is placed `margin` below the lowest child plane and
 // scale makes byte 255 reach `margin` above the highest, with

@@ -47,7 +47,9 @@ def check_closest(O, sc, So, rays, io, to, ig, tg, rt, n_ordinary):
             assert np.float32(t) == tg[i]
     same = tg == to
     assert np.array_equal((io == rt.NO_HIT)[same], (ig == rt.NO_HIT)[same])
-    assert (io[same] != ig[same]).mean() < 1e-2  # exact ties only
+    # exact-distance ties only (the Sponza-class stand-in has coplanar overlapping faces, and the
+    # refined leaves test their triangles in another order)
+    assert (io[same] != ig[same]).mean() < 3e-2
     return int(diff.size)
 
 
