@@ -513,6 +513,22 @@ __device__ __forceinline__ void load_item(const float4 *p, unsigned long long no
                  : "memory", "scc");
 }
 
+// 64 bytes through the scalar cache into SGPRs: used when every active lane of
+// the wave is at the same node or triangle (coherent rays near the top of the
+// tree), which takes that item off the vector memory path altogether.
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ u32x16 scalar_load64(const void *p)
+{
+    u32x16 n;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n) : "s"(p) : "memory");
+    return n;
+}
+__device__ __forceinline__ float4 f4_of(const u32x16 &n, int i)
+{
+    return make_float4(__uint_as_float(n[i]), __uint_as_float(n[i + 1]), __uint_as_float(n[i + 2]),
+                       __uint_as_float(n[i + 3]));
+}
+
 // compare-exchange of two (entry distance, child reference) pairs
 #define RTC_CE(ka, ca, kb, cb)                  \
     {                                           \
@@ -690,12 +706,21 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
     while (cur != kDone && steps < max_steps) {
         while (!(cur & kLeafBit) && steps < max_steps) {
             steps++;
-            const float4 *q = wn + (size_t)cur * 4;
-            const float4 a0 = q[0];
-            const float4 a1 = q[1];
-            const float4 a2 = q[2];
-            const uint4 ch = *reinterpret_cast<const uint4 *>(q + 3);
-            if (qwide_step<ANYHIT>(a0, a1, a2, ch, s, st, cur)) cur = st.sp ? st.pop() : kDone;
+            const unsigned ucur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
+            bool pop;
+            if (__ballot(cur != ucur) == 0) { // every lane still in this loop is at node ucur
+                const u32x16 n = scalar_load64(wn + (size_t)ucur * 4);
+                pop = qwide_step<ANYHIT>(f4_of(n, 0), f4_of(n, 4), f4_of(n, 8), make_uint4(n[12], n[13], n[14], n[15]),
+                                         s, st, cur);
+            } else {
+                const float4 *q = wn + (size_t)cur * 4;
+                const float4 a0 = q[0];
+                const float4 a1 = q[1];
+                const float4 a2 = q[2];
+                const uint4 ch = *reinterpret_cast<const uint4 *>(q + 3);
+                pop = qwide_step<ANYHIT>(a0, a1, a2, ch, s, st, cur);
+            }
+            if (pop) cur = st.sp ? st.pop() : kDone;
         }
         if ((cur & kLeafBit) && cur != kDone) {
             steps++;
@@ -709,19 +734,39 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
                 count = (cur & 7u) + 1u;
             }
             bool occluded = false;
-            for (unsigned i = 0; i < count; i++) {
-                const size_t base = (size_t)(first + i) * 3;
-                const float4 t0 = tris[base + 0];
-                const float4 t1 = tris[base + 1];
-                const float2 t2 = *reinterpret_cast<const float2 *>(tris + base + 2);
-                const float t = tri_test(t0, t1, t2, r.o, r.d);
-                if (t >= r.near_t && t < r.far_t) {
-                    if (ANYHIT) {
-                        occluded = true;
-                        break;
+            const unsigned ucur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
+            if (__ballot(cur != ucur) == 0) { // one leaf for the whole wave: triangles through the scalar cache
+                const unsigned ufirst = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
+                const unsigned ucount = (unsigned)__builtin_amdgcn_readfirstlane((int)count);
+                for (unsigned i = 0; i < ucount; i++) {
+                    const u32x16 n = scalar_load64(tris + (size_t)(ufirst + i) * 3); // 48 bytes used
+                    const float t = tri_test(f4_of(n, 0), f4_of(n, 4),
+                                             make_float2(__uint_as_float(n[8]), __uint_as_float(n[9])), r.o, r.d);
+                    if (!occluded && t >= r.near_t && t < r.far_t) {
+                        if (ANYHIT) {
+                            occluded = true;
+                        } else {
+                            r.far_t = t;
+                            s.hit = n[9];
+                        }
                     }
-                    r.far_t = t;
-                    s.hit = __float_as_uint(t2.y);
+                    if (ANYHIT && __ballot(!occluded) == 0) break;
+                }
+            } else {
+                for (unsigned i = 0; i < count; i++) {
+                    const size_t base = (size_t)(first + i) * 3;
+                    const float4 t0 = tris[base + 0];
+                    const float4 t1 = tris[base + 1];
+                    const float2 t2 = *reinterpret_cast<const float2 *>(tris + base + 2);
+                    const float t = tri_test(t0, t1, t2, r.o, r.d);
+                    if (t >= r.near_t && t < r.far_t) {
+                        if (ANYHIT) {
+                            occluded = true;
+                            break;
+                        }
+                        r.far_t = t;
+                        s.hit = __float_as_uint(t2.y);
+                    }
                 }
             }
             if (ANYHIT && occluded) {

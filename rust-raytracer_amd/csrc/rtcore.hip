@@ -539,6 +539,7 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     const uint32_t extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, xdn, xroot, xorder);
     std::vector<DevTri> xdt;
     make_tris(xorder, xdt);
+    xdt.resize(xdt.size() + 1, DevTri{}); // the scalar path reads a triangle as 64 bytes
     std::vector<float> n4((size_t)num_triangles * 4);
     for (uint32_t t = 0; t < num_triangles; t++) {
         n4[4 * (size_t)t + 0] = geom_normals[3 * (size_t)t + 0];
