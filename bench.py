@@ -124,14 +124,30 @@ def main():
     scene = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
     build_s = time.time() - t0
 
-    step_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    # Two frame buffers: while frame i is summed across the ranks (the collective runs on the
+    # backend's stream) frame i+1 is rendered into the other one.
+    step_accums = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    pending = [None, None]
     total_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     frame_spp = S * n_gpus if args.shard == "sample" else S   # samples of the whole frame per step
     last = {}
 
+    def retire(slot):
+        """Frame in buffer `slot` has been reduced: rank 0 adds it to the running image."""
+        if pending[slot] is not None:
+            work = pending[slot]
+            pending[slot] = None
+            if work is not True:
+                work.wait()
+            if rank == 0:
+                total_accum.add_(step_accums[slot])
+
     def step(i, visit_stats=False):
+        slot = i % 2
+        retire(slot)
+        step_accum = step_accums[slot]
         step_accum.zero_()
 
         def render_fn(acc, samples, sample_offset, shard_index, shard_count):
@@ -141,11 +157,14 @@ def main():
             last["st"] = st
             return st["total_rays"]
 
-        rays = node.node_render(render_fn, step_accum, rank, n_gpus, args.shard, frame_spp,
-                                sample_offset=i * frame_spp)
-        if rank == 0:
-            total_accum.add_(step_accum)
+        rays, work = node.node_render(render_fn, step_accum, rank, n_gpus, args.shard, frame_spp,
+                                      sample_offset=i * frame_spp, wait=False)
+        pending[slot] = work if work is not None else True
         return {"total_rays": rays}
+
+    def drain():
+        retire(0)
+        retire(1)
 
     def barrier():
         if world > 1:
@@ -154,10 +173,11 @@ def main():
 
     # counters for the roofline (un-timed, same workload)
     step(0, visit_stats=True)
+    drain()
     ext_st, con_st = ctx.last_stats_split()
-    total_accum.zero_()
     for i in range(args.warmup):
         step(i)
+    drain()
     total_accum.zero_()
 
     barrier()
@@ -176,6 +196,7 @@ def main():
         for k in ms:
             ms[k] += m[k]
             launches[k] += l[k]
+    drain()
     barrier()
     elapsed = time.perf_counter() - t_start
 

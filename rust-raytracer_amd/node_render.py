@@ -32,19 +32,27 @@ def shard_plan(rank, world, mode, samples, sample_offset=0):
     raise ValueError("mode must be 'sample' or 'tile'")
 
 
-def node_render(render_fn, accum, rank, world, mode, samples, sample_offset=0, dist=None):
+def node_render(render_fn, accum, rank, world, mode, samples, sample_offset=0, dist=None, wait=True):
     """Renders this rank's shard into `accum` (a zero-initialised torch tensor
     [H, W, 4] f32 that render_fn adds into) and sum-reduces it to rank 0.
 
     render_fn(accum, **plan) -> total rays traced by this rank (int).
     Returns this rank's ray count; after the call rank 0's accum holds the frame.
+
+    wait=False starts the reduce and returns (rays, work): the collective then
+    runs on the backend's own stream while the caller renders the next frame
+    into another buffer; `accum` must not be touched before work.wait()
+    (work is None when world == 1).
     """
     plan = shard_plan(rank, world, mode, samples, sample_offset)
     rays = 0
     if plan["samples"] > 0:
         rays = int(render_fn(accum, **plan))
+    work = None
     if world > 1:
         if dist is None:
             import torch.distributed as dist
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-    return rays
+        work = dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, async_op=not wait)
+    if wait:
+        return rays
+    return rays, work

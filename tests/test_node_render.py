@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, SPP, B = 48, 32, 5, 2
 
 
-def _worker(rank, world, mode, port, out_path):
+def _worker(rank, world, mode, port, out_path, overlapped=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -35,7 +35,18 @@ def _worker(rank, world, mode, port, out_path):
                          shard_index=shard_index, shard_count=shard_count, accum=a, nthreads=1)
         return st["total_rays"]
 
-    rays = nr.node_render(render_fn, accum, rank, world, mode, SPP)
+    if overlapped:
+        # two frames of the same image in flight: the second is rendered while the first is reduced
+        other = torch.zeros_like(accum)
+        first = SPP // 2
+        r0, w0 = nr.node_render(render_fn, accum, rank, world, mode, first, wait=False)
+        r1, w1 = nr.node_render(render_fn, other, rank, world, mode, SPP - first, sample_offset=first, wait=False)
+        w0.wait()
+        w1.wait()
+        accum += other
+        rays = r0 + r1
+    else:
+        rays = nr.node_render(render_fn, accum, rank, world, mode, SPP)
     t = torch.tensor([float(rays)], dtype=torch.float64)
     dist.all_reduce(t)
     if rank == 0:
@@ -59,6 +70,20 @@ def test_gloo_sharded_render(O, scenes, tmp_path, world, mode):
         assert np.array_equal(z["accum"], ref)                        # disjoint pixels: bit-identical
     else:
         assert np.allclose(z["accum"], ref, rtol=1e-5, atol=1e-6)     # f32 sums in a different order
+
+
+def test_gloo_overlapped_reduce(O, scenes, tmp_path):
+    """node_render(wait=False): frames reduced while the next one is rendered add up to the same image."""
+    out = str(tmp_path / "frame.npz")
+    port = 29500 + (os.getpid() % 2000) + 41
+    mp.spawn(_worker, args=(2, "sample", port, out, True), nprocs=2, join=True)
+    z = np.load(out)
+    sc = scenes.load("cornell-class")
+    S = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+    ref, st = S.render(sc.camera, sc.light, W, H, SPP, max_bounces=B, nthreads=1)
+    assert int(z["rays"][0]) == st["total_rays"]
+    assert np.array_equal(z["accum"][..., 3], ref[..., 3])
+    assert np.allclose(z["accum"], ref, rtol=1e-5, atol=1e-6)
 
 
 def test_shard_plan():
