@@ -268,6 +268,38 @@ int rt_render_device(rt_scene *scene, const rt_camera *camera, const rt_light *l
                      const rt_render_params *params, float *d_accum, rt_trace_stats *stats,
                      void *hip_stream);
 
+/* One-node multi-GPU rendering (no reference counterpart: the reference is one
+ * process; its tiles are independent, src/main.rs:157-161, which is what makes
+ * the split exact).  One process per GPU, full scene replica each.
+ *
+ * rt_shard_plan_make: the part of a frame of `samples` samples per pixel that
+ * rank `rank` of `world` renders.  mode RT_SHARD_SAMPLE: a contiguous range of
+ * the samples of every pixel (ranks below samples % world take one more);
+ * RT_SHARD_TILE: all samples of the tiles i with i % world == rank.  Pure host
+ * code. */
+#define RT_SHARD_SAMPLE 0
+#define RT_SHARD_TILE 1
+typedef struct rt_shard_plan {
+    uint32_t samples;
+    uint32_t sample_offset;
+    uint32_t shard_index;
+    uint32_t shard_count;
+} rt_shard_plan;
+int rt_shard_plan_make(uint32_t rank, uint32_t world, int mode, uint32_t samples, uint32_t sample_offset,
+                       rt_shard_plan *out);
+
+/* Renders this rank's part of the frame described by `frame` (its samples /
+ * sample_offset are the whole frame's; shard_index / shard_count are ignored)
+ * into d_accum (device, width*height*4 floats, added to) and, when nccl_comm is
+ * not NULL, sum-reduces d_accum to rank 0 of that communicator on hip_stream
+ * (in place; channel w sums the sample counts, src/main.rs:39).  nccl_comm is an
+ * ncclComm_t the host created over the node's GPUs (RCCL); librccl.so is
+ * opened on first use, so hosts that never call this do not need it.  stats
+ * counts this rank's rays only. */
+int rt_node_render(rt_scene *scene, const rt_camera *camera, const rt_light *light,
+                   const rt_render_params *frame, uint32_t rank, uint32_t world, int mode, void *nccl_comm,
+                   float *d_accum, rt_trace_stats *stats, void *hip_stream);
+
 /* Primary rays of a frame pass as StreamRays, generate_rays of
  * src/integrators/integrate_stream.rs:14-54 for every pixel of the frame:
  * rays[(y*width + x)*samples + s].  Used for per-ray parity checks. */

@@ -121,6 +121,9 @@ EXPORTS = {
                             C.POINTER(TraceStats)]),
     "rt_render_device": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(LightC), C.POINTER(RenderParams),
                                    _vp, C.POINTER(TraceStats), _vp]),
+    "rt_shard_plan_make": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _vp]),
+    "rt_node_render": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(LightC), C.POINTER(RenderParams), C.c_uint32,
+                                 C.c_uint32, C.c_int, _vp, _vp, C.POINTER(TraceStats), _vp]),
     "rt_generate_primary": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(RenderParams), _vp]),
     "rt_resolve": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
 }
@@ -194,6 +197,22 @@ def wide_bvh_host(nodes, root_ref, root_count):
     _check(_lib.rt_bvh_wide_host(_p(nodes), len(nodes), int(root_ref), int(root_count), _p(out), _p(qout),
                                  C.byref(n), C.byref(root), C.byref(depth)))
     return out[:n.value].copy(), qout[:n.value].copy(), int(root.value), int(depth.value)
+
+
+SHARD_SAMPLE, SHARD_TILE = 0, 1
+
+
+class ShardPlan(C.Structure):
+    _fields_ = [("samples", C.c_uint32), ("sample_offset", C.c_uint32), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32)]
+
+
+def shard_plan(rank, world, mode, samples, sample_offset=0):
+    """rt_shard_plan_make -> dict(samples, sample_offset, shard_index, shard_count)."""
+    out = ShardPlan()
+    _check(_lib.rt_shard_plan_make(int(rank), int(world), {"sample": 0, "tile": 1}.get(mode, mode), int(samples),
+                                   int(sample_offset), C.byref(out)))
+    return {n: int(getattr(out, n)) for n, _ in ShardPlan._fields_}
 
 
 class Context:
@@ -344,6 +363,18 @@ class Scene:
         cc, lc = camera_c(cam), light_c(light)
         _check(_lib.rt_render(self.h, C.byref(cc), C.byref(lc), C.byref(p), _p(accum), C.byref(st)))
         return accum, st.as_dict()
+
+    def node_render_device(self, cam, light, accum_ptr, width, height, samples, rank, world, mode, nccl_comm=None,
+                           max_bounces=2, tile_size=16, seed=1235468, sample_offset=0, samples_per_pass=0,
+                           stream=0, stats=True):
+        """rt_node_render: this rank's part of the frame, then (nccl_comm given) the sum-reduce to rank 0."""
+        p = RenderParams(width, height, samples, sample_offset, max_bounces, tile_size, 0, 1, samples_per_pass, 0, seed)
+        st = TraceStats()
+        cc, lc = camera_c(cam), light_c(light)
+        _check(_lib.rt_node_render(self.h, C.byref(cc), C.byref(lc), C.byref(p), int(rank), int(world),
+                                   {"sample": 0, "tile": 1}.get(mode, mode), _vp(nccl_comm), _vp(accum_ptr),
+                                   C.byref(st) if stats else None, _vp(stream)))
+        return st.as_dict() if stats else None
 
     # -- device-pointer calls (inputs resident in HBM) --------------------------
     def intersect_stream_device(self, rays_ptr, hits_ptr, n, stream=0, stats=False):

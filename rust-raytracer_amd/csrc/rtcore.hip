@@ -3,6 +3,7 @@
 // Host side only: argument checks, scene upload, workspace, pass planning and
 // kernel sequencing.  All device work is in kernels.hip.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1205,6 +1206,78 @@ extern "C" int rt_render(rt_scene *sc, const rt_camera *camera, const rt_light *
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(accum, ctx->io_a.p, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------
+// one-node multi-GPU
+
+extern "C" int rt_shard_plan_make(uint32_t rank, uint32_t world, int mode, uint32_t samples, uint32_t sample_offset,
+                                  rt_shard_plan *out)
+{
+    if (!out) return fail(RT_ERR_INVALID, "rt_shard_plan_make: out is NULL");
+    if (world < 1 || rank >= world) return fail(RT_ERR_INVALID, "rt_shard_plan_make: rank %u of world %u", rank, world);
+    if (mode == RT_SHARD_SAMPLE) {
+        const uint32_t base = samples / world, rem = samples % world;
+        out->samples = base + (rank < rem ? 1u : 0u);
+        out->sample_offset = sample_offset + rank * base + std::min(rank, rem);
+        out->shard_index = 0;
+        out->shard_count = 1;
+    } else if (mode == RT_SHARD_TILE) {
+        out->samples = samples;
+        out->sample_offset = sample_offset;
+        out->shard_index = rank;
+        out->shard_count = world;
+    } else {
+        return fail(RT_ERR_INVALID, "rt_shard_plan_make: mode %d is neither RT_SHARD_SAMPLE nor RT_SHARD_TILE", mode);
+    }
+    return RT_OK;
+}
+
+namespace {
+// ncclReduce(sendbuff, recvbuff, count, datatype, op, root, comm, stream) of librccl.so, bound at first use
+typedef int (*nccl_reduce_fn)(const void *, void *, size_t, int, int, int, void *, hipStream_t);
+typedef const char *(*nccl_error_fn)(int);
+nccl_reduce_fn g_nccl_reduce = nullptr;
+nccl_error_fn g_nccl_error = nullptr;
+std::once_flag g_nccl_once;
+constexpr int kNcclFloat32 = 7, kNcclSum = 0; // ncclDataType_t / ncclRedOp_t values of rccl.h
+} // namespace
+
+extern "C" int rt_node_render(rt_scene *sc, const rt_camera *camera, const rt_light *light,
+                              const rt_render_params *frame, uint32_t rank, uint32_t world, int mode, void *nccl_comm,
+                              float *d_accum, rt_trace_stats *stats, void *hip_stream)
+{
+    if (!sc || !camera || !light || !frame || !d_accum) return fail(RT_ERR_INVALID, "rt_node_render: NULL argument");
+    rt_shard_plan plan{};
+    int rc = rt_shard_plan_make(rank, world, mode, frame->samples, frame->sample_offset, &plan);
+    if (rc != RT_OK) return rc;
+    rt_render_params p = *frame;
+    p.samples = plan.samples;
+    p.sample_offset = plan.sample_offset;
+    p.shard_index = plan.shard_index;
+    p.shard_count = plan.shard_count;
+    if (p.samples > 0) {
+        rc = rt_render_device(sc, camera, light, &p, d_accum, stats, hip_stream);
+        if (rc != RT_OK) return rc;
+    }
+    if (!nccl_comm) return RT_OK;
+    std::call_once(g_nccl_once, [] {
+        void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            g_nccl_reduce = (nccl_reduce_fn)dlsym(lib, "ncclReduce");
+            g_nccl_error = (nccl_error_fn)dlsym(lib, "ncclGetErrorString");
+        }
+    });
+    if (!g_nccl_reduce) return fail(RT_ERR_HIP, "rt_node_render: librccl.so (ncclReduce) is not available: %s", dlerror());
+    rc = ctx_set_device(sc->ctx);
+    if (rc != RT_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream; // the stream the render was enqueued on
+    const size_t count = (size_t)frame->width * frame->height * 4;
+    const int nr = g_nccl_reduce(d_accum, d_accum, count, kNcclFloat32, kNcclSum, 0, nccl_comm, s);
+    if (nr != 0)
+        return fail(RT_ERR_HIP, "rt_node_render: ncclReduce failed: %s", g_nccl_error ? g_nccl_error(nr) : "unknown");
     return RT_OK;
 }
 

@@ -86,6 +86,68 @@ def test_gloo_overlapped_reduce(O, scenes, tmp_path):
     assert np.allclose(z["accum"], ref, rtol=1e-5, atol=1e-6)
 
 
+def test_c_abi_shard_plan_matches_python(rt):
+    nr = importlib.import_module("rust-raytracer_amd.node_render")
+    for world in (1, 2, 3, 8):
+        for mode in ("sample", "tile"):
+            for samples, off in ((128, 0), (5, 7), (2, 1), (0, 0)):
+                for rank in range(world):
+                    assert rt.shard_plan(rank, world, mode, samples, off) == nr.shard_plan(rank, world, mode, samples, off)
+    with pytest.raises(rt.RtError):
+        rt.shard_plan(2, 2, "sample", 8)
+    with pytest.raises(rt.RtError):
+        rt.shard_plan(0, 1, 5, 8)
+
+
+@pytest.mark.gpu
+def test_rt_node_render_with_rccl(rt, scenes):
+    """rt_node_render on a one-rank RCCL communicator: the library opens librccl.so itself and the
+    in-place ncclReduce leaves rank 0's frame equal to what rt_render_device produces; virtual ranks
+    rendered one after the other add up to the unsharded frame."""
+    import ctypes as C
+    rccl = C.CDLL("librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        sc = scenes.load("test-mesh", n_tris=3000, seed=5)
+        ctx = rt.Context(0)
+        Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+        W2, H2, spp = 64, 40, 6
+        whole = torch.zeros((H2, W2, 4), dtype=torch.float32, device="cuda:0")
+        st = Sg.node_render_device(sc.camera, sc.light, whole.data_ptr(), W2, H2, spp, 0, 1, "sample",
+                                   nccl_comm=comm.value)
+        torch.cuda.synchronize()
+        ref = torch.zeros_like(whole)
+        st_ref = Sg.render_device(sc.camera, sc.light, ref.data_ptr(), W2, H2, spp)
+        torch.cuda.synchronize()
+        assert st["total_rays"] == st_ref["total_rays"]
+        assert torch.equal(whole, ref)
+        for mode in ("sample", "tile"):
+            acc = torch.zeros_like(whole)
+            rays = 0
+            for rank in range(3):   # three virtual ranks into one buffer, no communicator
+                rays += Sg.node_render_device(sc.camera, sc.light, acc.data_ptr(), W2, H2, spp, rank, 3, mode)["total_rays"]
+            torch.cuda.synchronize()
+            assert rays == st_ref["total_rays"]
+            if mode == "tile":
+                assert torch.equal(acc, ref)
+            else:
+                assert torch.allclose(acc, ref, rtol=1e-5, atol=1e-6)
+        Sg.close()
+        ctx.close()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_shard_plan():
     nr = importlib.import_module("rust-raytracer_amd.node_render")
     for world in (1, 2, 3, 8):
