@@ -239,6 +239,23 @@ int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t roo
                      rt_wide_node *out, rt_qwide_node *qout, uint32_t *num_wide, uint32_t *wide_root_ref,
                      uint32_t *wide_depth);
 
+/* Finer leaves for the wide tree (no reference counterpart; the reference stops
+ * at 8 triangles per leaf, src/bvh/build.rs:80-81).  Takes the canonical flat
+ * tree and leaf order of rt_bvh_build_host and returns a copy in which every
+ * leaf of 2..8 triangles holding more than max_tris is replaced by a small
+ * binary subtree over its own triangles (ordered by centroid on the leaf's
+ * largest centroid-extent axis, cut where area(A)*|A| + area(B)*|B| is least;
+ * child boxes are the exact unions of the triangles' vertex bounds).  The
+ * original nodes keep their indices, new nodes are appended; xorder is a
+ * permutation of order that only moves triangles inside their reference leaf.
+ * xnodes must hold num_nodes + num_triangles entries, xorder num_triangles.
+ * rt_scene_create builds the wide tree over exactly this (max_tris = 3). */
+int rt_bvh_refine_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                       uint32_t num_triangles, const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref,
+                       uint32_t root_count, const uint32_t *order, uint32_t max_tris, rt_flat_node *xnodes,
+                       uint32_t *xorder, uint32_t *num_xnodes, uint32_t *xroot_ref, uint32_t *xroot_count,
+                       uint32_t *extra_depth);
+
 /* Bvh::intersect_stream, src/bvh/intersect_stream.rs:10-15: closest hit for n
  * rays.  hits[i] = mesh triangle id or RT_NO_HIT; rays[i].origin_far[3] is
  * shrunk to the hit distance.  Accept rule near <= t < far

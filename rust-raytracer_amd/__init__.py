@@ -110,6 +110,9 @@ EXPORTS = {
                                     C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
     "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32),
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_bvh_refine_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp,
+                                     C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_scene_stats": (C.c_int, [_vp, C.POINTER(BvhStats)]),
     "rt_scene_get_info": (C.c_int, [_vp, C.POINTER(SceneInfo)]),
     "rt_scene_get_flat": (C.c_int, [_vp, _vp, _vp]),
@@ -197,6 +200,22 @@ def wide_bvh_host(nodes, root_ref, root_count):
     _check(_lib.rt_bvh_wide_host(_p(nodes), len(nodes), int(root_ref), int(root_count), _p(out), _p(qout),
                                  C.byref(n), C.byref(root), C.byref(depth)))
     return out[:n.value].copy(), qout[:n.value].copy(), int(root.value), int(depth.value)
+
+
+def refine_bvh_host(positions, indices, nodes, root_ref, root_count, order, max_tris=3):
+    """rt_bvh_refine_host -> (refined flat nodes, refined leaf order, root ref, root count, extra depth)."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    nt = idx.shape[0]
+    xnodes = np.zeros(len(nodes) + nt, dtype=NODE_DTYPE)
+    xorder = np.zeros(nt, dtype=np.uint32)
+    n, root, count, extra = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _check(_lib.rt_bvh_refine_host(_p(pos), pos.shape[0], _p(idx), nt, _p(nodes), len(nodes), int(root_ref),
+                                   int(root_count), _p(order), int(max_tris), _p(xnodes), _p(xorder), C.byref(n),
+                                   C.byref(root), C.byref(count), C.byref(extra)))
+    return xnodes[:n.value].copy(), xorder, int(root.value), int(count.value), int(extra.value)
 
 
 SHARD_SAMPLE, SHARD_TILE = 0, 1

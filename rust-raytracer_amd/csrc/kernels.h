@@ -15,6 +15,10 @@
 
 // occupancy the trace kernels are compiled for (waves per SIMD): bounds the
 // VGPR allocation; together with the LDS stack it sets resident blocks per CU
+// any-hit launches on the wide tree: visit hit children nearest first (1) or in slot order (0)
+#ifndef RTC_ANYHIT_SORTED
+#define RTC_ANYHIT_SORTED 0
+#endif
 #ifndef RTC_TRACE_WAVES_PER_SIMD
 #define RTC_TRACE_WAVES_PER_SIMD 5
 #endif

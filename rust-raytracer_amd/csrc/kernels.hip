@@ -578,7 +578,7 @@ __device__ __forceinline__ bool qwide_step(const float4 a0, const float4 a1, con
     float k2 = n2 <= f2 ? n2 : inf;
     float k3 = n3 <= f3 ? n3 : inf;
     unsigned c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-    if (!ANYHIT) { // stable 4-input sorting network on the entry distance
+    if (!ANYHIT || RTC_ANYHIT_SORTED) { // stable 4-input sorting network on the entry distance
         RTC_CE(k0, c0, k1, c1);
         RTC_CE(k2, c2, k3, c3);
         RTC_CE(k0, c0, k2, c2);

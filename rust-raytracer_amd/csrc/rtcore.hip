@@ -680,6 +680,59 @@ extern "C" int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, u
     return RT_OK;
 }
 
+extern "C" int rt_bvh_refine_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                                  uint32_t num_triangles, const rt_flat_node *nodes, uint32_t num_nodes,
+                                  uint32_t root_ref, uint32_t root_count, const uint32_t *order, uint32_t max_tris,
+                                  rt_flat_node *xnodes, uint32_t *xorder, uint32_t *num_xnodes, uint32_t *xroot_ref,
+                                  uint32_t *xroot_count, uint32_t *extra_depth)
+{
+    if (!positions || !indices || (num_nodes && !nodes) || !order || !xnodes || !xorder || !num_xnodes || !xroot_ref ||
+        !xroot_count)
+        return fail(RT_ERR_INVALID, "rt_bvh_refine_host: NULL argument");
+    if (max_tris < 1 || max_tris > 8) return fail(RT_ERR_INVALID, "rt_bvh_refine_host: max_tris %u outside [1, 8]", max_tris);
+    for (size_t i = 0; i < (size_t)num_triangles * 3; i++)
+        if (indices[i] >= num_vertices) return fail(RT_ERR_INVALID, "rt_bvh_refine_host: index out of range");
+    for (uint32_t i = 0; i < num_triangles; i++)
+        if (order[i] >= num_triangles) return fail(RT_ERR_INVALID, "rt_bvh_refine_host: order[%u] out of range", i);
+    try {
+        std::vector<DevNode> dn, xdn;
+        std::vector<BigLeaf> big;
+        const uint32_t root = make_dev_nodes(nodes, num_nodes, root_ref, root_count, dn, big);
+        std::vector<uint32_t> ord(order, order + num_triangles), xord;
+        uint32_t xroot = root;
+        const uint32_t extra = refine_leaves(dn, root, positions, indices, ord, max_tris, xdn, xroot, xord);
+        // back to the canonical encoding: leaf = bit 31 | first slot, with a separate count
+        auto unpack = [&](uint32_t ref, uint32_t &out_ref, uint32_t &out_count) {
+            if (!(ref & kLeafBit)) {
+                out_ref = ref;
+                out_count = 0;
+            } else if (ref & kBigLeafBit) {
+                const BigLeaf &bl = big[ref & 0x3FFFFFFFu];
+                out_ref = kLeafBit | bl.first;
+                out_count = bl.count;
+            } else {
+                out_ref = kLeafBit | ((ref >> 3) & (kMaxPackedFirst - 1u));
+                out_count = (ref & 7u) + 1u;
+            }
+        };
+        for (size_t i = 0; i < xdn.size(); i++) {
+            rt_flat_node &o = xnodes[i];
+            memcpy(o.bx, xdn[i].bx, sizeof o.bx);
+            memcpy(o.by, xdn[i].by, sizeof o.by);
+            memcpy(o.bz, xdn[i].bz, sizeof o.bz);
+            unpack(xdn[i].left, o.left, o.left_count);
+            unpack(xdn[i].right, o.right, o.right_count);
+        }
+        memcpy(xorder, xord.data(), xord.size() * sizeof(uint32_t));
+        *num_xnodes = (uint32_t)xdn.size();
+        unpack(xroot, *xroot_ref, *xroot_count);
+        if (extra_depth) *extra_depth = extra;
+    } catch (const std::exception &ex) {
+        return fail(RT_ERR_NOMEM, "rt_bvh_refine_host: %s", ex.what());
+    }
+    return RT_OK;
+}
+
 extern "C" void rt_scene_destroy(rt_scene *sc)
 {
     if (!sc) return;

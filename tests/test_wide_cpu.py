@@ -120,3 +120,55 @@ def test_wide_host_rejects_bad_tree(rt):
     nodes[0]["right_count"] = 1
     with pytest.raises(rt.RtError):
         rt.wide_bvh_host(nodes, 0, 0)
+
+
+@pytest.mark.parametrize("max_tris", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 3000, "seed": 4})])
+def test_refined_leaves(rt, scenes, name, kw, max_tris):
+    """rt_bvh_refine_host: original nodes keep index and boxes, every reference leaf keeps its slot
+    range and its set of triangles, new leaves hold at most max_tris triangles (unless their
+    centroids coincide), and every new child box is exactly the bound of the triangles below it."""
+    sc = scenes.load(name, **kw)
+    nodes, order, info, stats = rt.build_bvh_host(sc.positions, sc.indices)
+    xn, xorder, xroot, xcount, extra = rt.refine_bvh_host(sc.positions, sc.indices, nodes, info["root_ref"],
+                                                          info["root_count"], order, max_tris)
+    assert len(xn) >= len(nodes) and xroot == info["root_ref"] and extra <= 7
+    assert sorted(xorder.tolist()) == sorted(order.tolist())
+    for k in ("bx", "by", "bz"):
+        assert np.array_equal(xn[k][:len(nodes)], nodes[k])
+    P, I = sc.positions, sc.indices
+
+    def bound(first, count):
+        v = P[I[xorder[first:first + count]].reshape(-1)]
+        return v.min(axis=0), v.max(axis=0)
+
+    def subtree(ref, count):
+        """(first slot, triangle count, lo, hi) of the triangles below a refined child."""
+        if ref & LEAF:
+            first = ref & 0x7FFFFFFF
+            lo, hi = bound(first, count)
+            if count > max_tris:   # only leaves whose centroids give nothing to order by stay larger
+                c = P[I[xorder[first:first + count]]].mean(axis=1)
+                assert count > 8 or np.ptp(c, axis=0).max() < 1e-6
+            return first, count, lo, hi
+        assert ref >= len(nodes)   # new nodes are appended
+        n = xn[ref]
+        fl, cl, lol, hil = subtree(int(n["left"]), int(n["left_count"]))
+        fr, cr, lor, hir = subtree(int(n["right"]), int(n["right_count"]))
+        assert fr == fl + cl       # contiguous slots, left to right
+        for lane, lo, hi in ((0, lol, hil), (1, lor, hir)):
+            got_lo = np.array([n["bx"][lane], n["by"][lane], n["bz"][lane]])
+            got_hi = np.array([n["bx"][lane + 2], n["by"][lane + 2], n["bz"][lane + 2]])
+            assert np.array_equal(got_lo, lo) and np.array_equal(got_hi, hi)
+        return fl, cl + cr, np.minimum(lol, lor), np.maximum(hil, hir)
+
+    for i in range(len(nodes)):
+        for side in ("left", "right"):
+            ref, cnt = int(nodes[i][side]), int(nodes[i][side + "_count"])
+            xref, xcnt = int(xn[i][side]), int(xn[i][side + "_count"])
+            if not ref & LEAF:
+                assert xref == ref
+                continue
+            first, count, _, _ = subtree(xref, xcnt)
+            assert first == (ref & 0x7FFFFFFF) and count == cnt
+            assert sorted(xorder[first:first + count].tolist()) == sorted(order[first:first + count].tolist())
