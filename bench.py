@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sponza-class", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step")
+    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=None)
@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--shard", default="sample", choices=["sample", "tile"],
                     help="sample: every rank renders --spp samples of the whole frame per step (weak scaling); "
                          "tile: the step's --spp samples are split by tile (strong scaling)")
+    ap.add_argument("--max-paths", type=int, default=None, help="path slots per render pass (library default 2^24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -120,6 +121,8 @@ def main():
     W, H, S = args.width, args.height, args.spp
 
     ctx = rt.Context(dev_index)
+    if args.max_paths:
+        ctx.set_max_paths(args.max_paths)
     t0 = time.time()
     scene = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
     build_s = time.time() - t0

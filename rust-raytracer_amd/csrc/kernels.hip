@@ -1364,7 +1364,8 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(CameraDev cam, Pass
         rays[idx] = q;
         PathInfo pi;
         pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
-        pi.slot = slot;
+        // radiance index: sample-major over the pass's pixel slots (see accumulate_kernel)
+        pi.slot = sidx * (ps.num_slots / ps.samples_per_pass) + slot / ps.samples_per_pass;
         pi.pixel = pixel;
         pi.sample = gs;
         pi.bounces = 0;
@@ -1549,11 +1550,13 @@ __global__ __launch_bounds__(256) void accumulate_kernel(PassDev ps, const float
     const unsigned y = ty * ps.tile_size + pin / ps.tile_size;
     if (x >= ps.width || y >= ps.height) return;
     float r = 0.f, g = 0.f, b = 0.f;
-    const size_t base = (size_t)p * ps.samples_per_pass;
+    // radiance slots are sample-major (sample s of pass pixel p at s * pixels + p): neighbouring
+    // threads read neighbouring words whatever the samples per pass
+    const size_t pixels = (size_t)ps.tile_count * ts2;
     for (unsigned s = 0; s < ps.samples_this_pass; s++) {
-        r += rad_r[base + s];
-        g += rad_g[base + s];
-        b += rad_b[base + s];
+        r += rad_r[s * pixels + p];
+        g += rad_g[s * pixels + p];
+        b += rad_b[s * pixels + p];
     }
     float4 *dst = reinterpret_cast<float4 *>(accum) + ((size_t)y * ps.width + x);
     float4 v = *dst;

@@ -127,7 +127,7 @@ struct rt_ctx {
     std::vector<uint32_t> est_counts; // [0..nb] ray queues, then [0..nb-1] shadow queues
     uint64_t est_key[3] = {0, 0, 0};  // plan the estimate belongs to: scene, slots, depths
     uint64_t pending_key[3] = {0, 0, 0};
-    uint64_t max_paths = 1ull << 24;
+    uint64_t max_paths = 1ull << 25;
     DevBuf io_a, io_b; // staging for the host-buffer entry points
     std::vector<TimedLaunch> pool;
     size_t used = 0;

@@ -11,7 +11,7 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  case " ${PASSES:-1 2 3 4 5 6 7 8 9} " in *" $i "*) ;; *) continue;; esac
+  case " ${PASSES:-1 2 3 4 5 6 7 8 9 10 11} " in *" $i "*) ;; *) continue;; esac
   rm -rf $OUT/p$i
   timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 2 --warmup 0 --workload $WL --no-cpu-baseline ${BENCH_ARGS} > $OUT/p$i.log 2>&1 || { tail -20 $OUT/p$i.log; exit 1; }
   echo "pass $i ok: $set"
@@ -25,6 +25,8 @@ TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PEN
 GRBM_GUI_ACTIVE GRBM_COUNT
 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE
 TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
+TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum GRBM_GUI_ACTIVE
+TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_UTCL1_STALL_MULTI_MISS_sum GRBM_GUI_ACTIVE
 SETS
 python3 scripts/pmc_summary.py $OUT > $OUT/summary.txt
 cat $OUT/summary.txt
