@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sponza-class", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step")
+    ap.add_argument("--spp", type=int, default=32, help="samples per pixel per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=None)
@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--shard", default="sample", choices=["sample", "tile"],
                     help="sample: every rank renders --spp samples of the whole frame per step (weak scaling); "
                          "tile: the step's --spp samples are split by tile (strong scaling)")
-    ap.add_argument("--max-paths", type=int, default=None, help="path slots per render pass (library default 2^24)")
+    ap.add_argument("--max-paths", type=int, default=None, help="path slots per render pass (library default 2^26)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()

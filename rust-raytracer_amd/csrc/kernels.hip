@@ -1135,7 +1135,23 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
                     ray = tl.perm[idx];
                     if (ray >= n) ray = idx; // never index outside the queue, whatever the permutation holds
                 }
-                lane_begin(s, MODE >= 2 ? sc.wroot_ref : sc.root_ref, io.load(ray), ray);
+                RayRegs loaded = io.load(ray);
+                if (MODE >= 2) {
+                    // An exactly axis-parallel ray (cosine sampling returns the surface normal once
+                    // in 2^24 draws, and floors and walls are axis aligned) has 1/d = +-inf, and
+                    // plane*inf - o*inf is +-inf or NaN by the signs of plane and o: with far still
+                    // infinite almost every box passes and one such ray walks millions of nodes (the
+                    // reference does the same on a CPU thread, where it goes unnoticed).  The wide
+                    // forms bound the reciprocal the way the reference's packet rays do
+                    // (src/simd_ray.rs:46-47): |d| < 1e-24 counts as 1e-24, which makes the slab
+                    // test of such an axis a proper inside/outside test.  Triangle tests use d itself.
+                    const float tiny = 1e-24f;
+                    const float dx = fabsf(loaded.d.x) < tiny ? copysignf(tiny, loaded.d.x) : loaded.d.x;
+                    const float dy = fabsf(loaded.d.y) < tiny ? copysignf(tiny, loaded.d.y) : loaded.d.y;
+                    const float dz = fabsf(loaded.d.z) < tiny ? copysignf(tiny, loaded.d.z) : loaded.d.z;
+                    loaded.rd = v3(1.f / dx, 1.f / dy, 1.f / dz);
+                }
+                lane_begin(s, MODE >= 2 ? sc.wroot_ref : sc.root_ref, loaded, ray);
                 st.sp = 0;
                 if (STATS) {
                     nrays++;

@@ -127,7 +127,7 @@ struct rt_ctx {
     std::vector<uint32_t> est_counts; // [0..nb] ray queues, then [0..nb-1] shadow queues
     uint64_t est_key[3] = {0, 0, 0};  // plan the estimate belongs to: scene, slots, depths
     uint64_t pending_key[3] = {0, 0, 0};
-    uint64_t max_paths = 1ull << 25;
+    uint64_t max_paths = 1ull << 26;
     DevBuf io_a, io_b; // staging for the host-buffer entry points
     std::vector<TimedLaunch> pool;
     size_t used = 0;
@@ -264,6 +264,10 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_MIN_ACTIVE_CONNECT")) {
         int v = atoi(env);
         if (v >= 1 && v <= 64) ctx->min_active[1] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_COOP_CAP")) {
+        int v = atoi(env);
+        if (v >= 256 && v <= (1 << 20)) ctx->coop_cap = (unsigned)v;
     }
     int rc = ctx->dstats.ensure(2 * sizeof(StatsDev));
     if (rc == RT_OK) rc = ctx->fetch.ensure(kFetchUints * sizeof(unsigned));
