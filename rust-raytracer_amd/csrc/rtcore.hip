@@ -106,8 +106,8 @@ struct rt_ctx {
     DevBuf fetch; // ray-fetch counters of the stream entry points
     DevBuf coop;  // wave-private work stacks of the cooperative straggler path
     unsigned coop_cap = 2048;    // entries per wave
-    unsigned coop_steps = 256;   // a ray is handed to its whole wave after this many loop iterations
-    unsigned min_active[2] = {48, 48}; // [0] closest-hit, [1] any-hit launches
+    unsigned coop_steps = 4096;  // a ray is handed to its whole wave after this many loop iterations
+    unsigned min_active[2] = {40, 40}; // [0] closest-hit, [1] any-hit launches
     // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
     // while-while form wins), [1] for deeper launches and the stream entry points
     unsigned trav_mode[2] = {3, 2};

@@ -9,7 +9,7 @@ Moeller-Trumbore with a division), so where two surfaces meet within rounding
 the marginally closer triangle and the other not.  Bar for such rays: the same
 hit/miss decision, hit distances within 2e-6 relative (a few ulps), ids equal
 wherever the distances are equal, and only a small fraction of rays affected.
-With the library default (256 steps) only rays that need more steps than that
+With the library default (4096 steps) only rays that need more steps than that
 take this path at all."""
 import numpy as np
 import pytest
@@ -49,7 +49,7 @@ def test_coop_trace_parity(O, rt, ctx_default, scenes, steps, mode):
             assert np.array_equal(oo, og)
             Sg.close()
     finally:
-        ctx.set_option("coop_steps", 256)
+        ctx.set_option("coop_steps", 4096)
         ctx.set_option("traversal_stream", 1)
 
 
@@ -71,7 +71,7 @@ def test_coop_render_parity(O, rt, ctx_default, scenes):
             rmse = float(np.sqrt(np.mean((ag[..., :3] / spp - ao[..., :3] / spp) ** 2)))
             assert rmse < 2e-3, rmse
     finally:
-        ctx.set_option("coop_steps", 256)
+        ctx.set_option("coop_steps", 4096)
     Sg.close()
 
 

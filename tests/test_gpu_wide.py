@@ -54,7 +54,7 @@ def check_closest(O, sc, So, rays, io, to, ig, tg, rt, n_ordinary):
 
 
 @pytest.mark.parametrize("form", [2, 3])
-@pytest.mark.parametrize("coop", [0, 5, 256])
+@pytest.mark.parametrize("coop", [0, 5, 4096])
 def test_wide_trace_parity(O, rt, ctx_default, scenes, coop, form):
     ctx = ctx_default
     ctx.set_option("traversal_stream", form)
@@ -89,7 +89,7 @@ def test_wide_trace_parity(O, rt, ctx_default, scenes, coop, form):
                 assert np.array_equal(og[bad].astype(bool), ib != rt.NO_HIT)
             Sg.close()
     finally:
-        ctx.set_option("coop_steps", 256)
+        ctx.set_option("coop_steps", 4096)
         ctx.set_option("traversal_stream", 1)
 
 
