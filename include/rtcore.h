@@ -148,10 +148,10 @@ int rt_ctx_create(int device_id, rt_ctx **out);
 void rt_ctx_destroy(rt_ctx *ctx);
 /* Tuning knobs (no reference counterpart).  Names and ranges:
  *   "coop_steps"        loop iterations after which a ray is finished by its whole
- *                       wave (0 = never).  Rays handled that way keep their exact
+ *                       wave (0 = never; default 4096).  Rays handled that way keep their exact
  *                       hit distance; their visit counters and the id on an
  *                       exact-distance tie may differ from the single-lane walk.
- *   "min_active"        1..64, a wave fetches new rays when fewer lanes are busy
+ *   "min_active"        1..64, a wave fetches new rays when fewer lanes are busy (default 40)
  *   "traversal_depth0", "traversal_deep", "traversal_stream"   traversal form of the
  *                       depth-0 launches of rt_render, of its deeper launches, and of the
  *                       stream entry points: 0 = while-while loop on the binary tree, 1 = one
@@ -159,16 +159,20 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       item per iteration on the quantized 4-wide tree, 3 = while-while loop
  *                       on the quantized 4-wide tree.  Defaults 3, 2, 1.  Forms 0 and 1 walk
  *                       the reference's tree in the reference's order (exact distances, ids
- *                       and visit counters); 2 and 3 test a superset of its triangles in
- *                       another order: same distances except where two surfaces meet within
- *                       rounding, ids may differ on exact ties, no visit counters.  Calls
- *                       that ask for visit counters always run form 0 or 1.
+ *                       and visit counters); 2 and 3 walk finer, conservatively quantized
+ *                       boxes over the same triangles in another order: same distances except
+ *                       where two surfaces meet within rounding, ids may differ on exact
+ *                       ties, no visit counters, and 1/d is bounded as in the reference's
+ *                       packet rays (src/simd_ray.rs:46-47) so that axis-parallel rays are
+ *                       culled properly.  Calls that ask for visit counters always run form
+ *                       0 or 1.
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
  *   "sort_bits"         3..30 key bits that take part in the order
  *   "timing"            0/1 per-launch HIP events */
 int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value);
 
-/* Upper bound of paths per render pass (workspace is sized from it lazily). */
+/* Upper bound of paths per render pass (default 2^26; the workspace, about
+ * 212 bytes per path, is sized lazily from what a call needs). */
 int rt_ctx_set_max_paths(rt_ctx *ctx, uint64_t max_paths);
 
 /* Bvh::build, src/bvh/build.rs:45-63 (binned SAH, 8 buckets, leaf <= 8) on the
