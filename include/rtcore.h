@@ -166,6 +166,9 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       packet rays (src/simd_ray.rs:46-47) so that axis-parallel rays are
  *                       culled properly.  Calls that ask for visit counters always run form
  *                       0 or 1.
+ *   "fuse_primary"      0/1 (default 1): depth 0 of rt_render without ray and PathInfo queues;
+ *                       the extend launch makes the camera rays itself.  Same image bit for
+ *                       bit; not used by calls that ask for visit counters.
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
  *   "sort_bits"         3..30 key bits that take part in the order
  *   "timing"            0/1 per-launch HIP events */

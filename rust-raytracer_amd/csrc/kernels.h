@@ -81,6 +81,13 @@ struct PassDev {
 };
 
 struct ShadeArgs {
+    // depth 0 without queues (primary != 0): ray and PathInfo of entry i are rebuilt from pass slot
+    // i, its hit distance is hit_t[i], and the entry count is n_in_val (n_in null)
+    unsigned primary;
+    unsigned n_in_val;
+    const float *hit_t;
+    CameraDev cam;
+    PassDev ps;
     const QRay *rays_in;
     const PathInfo *infos_in;
     const uint32_t *hit_ids;
@@ -119,6 +126,9 @@ void launch_extend(bool stats, const SceneDev &sc, QRay *rays, unsigned *hit_ids
 void launch_connect(bool stats, const SceneDev &sc, const QRay *rays, const ShadowInfo *infos,
                     const unsigned *n_ptr, unsigned n_upper, float *rad_r, float *rad_g, float *rad_b,
                     const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream);
+void launch_extend_primary(const SceneDev &sc, const CameraDev &cam, const PassDev &ps, unsigned *hit_ids,
+                           float *hit_t, const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream);
+void launch_set_count(unsigned *dst, unsigned value, hipStream_t stream);
 void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream);
 void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,
                      float *rad_r, float *rad_g, float *rad_b, hipStream_t stream);

@@ -1092,6 +1092,8 @@ struct QueueIO { // render pipeline queues
     }
 };
 
+struct PrimaryIO; // depth-0 closest-hit launches that make their own camera rays (defined below the camera code)
+
 template <bool ANYHIT, bool STATS, int MODE, class IO>
 __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel(SceneDev sc, IO io, const unsigned *n_ptr, unsigned n_val,
                                                       TraceLaunch tl)
@@ -1153,6 +1155,16 @@ __global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel
                 }
                 lane_begin(s, MODE >= 2 ? sc.wroot_ref : sc.root_ref, loaded, ray);
                 st.sp = 0;
+                // A ray with a NaN or infinite origin or direction component cannot be accepted by
+                // the triangle test (its determinant is not finite), but NaN slab distances drop every
+                // box constraint and it would walk the whole tree.  It is retired as the miss it is;
+                // with visit counters requested it is walked, so that the counters stay those of the
+                // reference's traversal.  (Slots outside the image arrive here as such rays.)
+                if (!STATS) {
+                    const float probe = ((loaded.o.x * 0.f + loaded.o.y * 0.f) + loaded.o.z * 0.f) +
+                                        ((loaded.d.x * 0.f + loaded.d.y * 0.f) + loaded.d.z * 0.f);
+                    if (!(probe == 0.f)) s.cur = kDone;
+                }
                 if (STATS) {
                     nrays++;
                     cnt.ray_start = cnt.inner + cnt.tris;
@@ -1337,6 +1349,37 @@ __device__ __forceinline__ bool slot_to_pixel(const PassDev &ps, unsigned slot, 
     return (x < ps.width) && (y < ps.height) && (s < ps.samples_this_pass);
 }
 
+// Primary path of pass slot `slot`: the camera ray of generate_rays
+// (src/integrators/integrate_stream.rs:14-54) and its PathInfo.  False for slots
+// outside the image or beyond the pass's samples.
+__device__ __forceinline__ bool primary_path(const CameraDev &cam, const PassDev &ps, unsigned slot, QRay &q,
+                                             PathInfo &pi)
+{
+    unsigned x, y, sidx;
+    if (!slot_to_pixel(ps, slot, x, y, sidx)) return false;
+    const unsigned pixel = y * ps.width + x;
+    const unsigned gs = ps.sample_base + sidx;
+    const unsigned key = rng_key(ps.seed_key, pixel, gs);
+    const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
+    const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
+    q.o[0] = cam.eye[0];
+    q.o[1] = cam.eye[1];
+    q.o[2] = cam.eye[2];
+    q.near_t = 0.f;
+    q.d[0] = d.x;
+    q.d[1] = d.y;
+    q.d[2] = d.z;
+    q.far_t = __builtin_inff();
+    pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
+    // radiance index: sample-major over the pass's pixel slots (see accumulate_kernel)
+    pi.slot = sidx * (ps.num_slots / ps.samples_per_pass) + slot / ps.samples_per_pass;
+    pi.pixel = pixel;
+    pi.sample = gs;
+    pi.bounces = 0;
+    pi.pad = 0;
+    return true;
+}
+
 __global__ __launch_bounds__(kGenBlock) void generate_kernel(CameraDev cam, PassDev ps, QRay *rays,
                                                             PathInfo *infos, unsigned *n_out, float *rad_r,
                                                             float *rad_g, float *rad_b)
@@ -1360,32 +1403,11 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(CameraDev cam, Pass
             rad_g[slot] = 0.f;
             rad_b[slot] = 0.f;
         }
-        unsigned x, y, sidx;
-        if (!slot_to_pixel(ps, slot, x, y, sidx)) continue;
-        const unsigned idx = pos[0][it];
-        const unsigned pixel = y * ps.width + x;
-        const unsigned gs = ps.sample_base + sidx;
-        const unsigned key = rng_key(ps.seed_key, pixel, gs);
-        const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
-        const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
         QRay q;
-        q.o[0] = cam.eye[0];
-        q.o[1] = cam.eye[1];
-        q.o[2] = cam.eye[2];
-        q.near_t = 0.f;
-        q.d[0] = d.x;
-        q.d[1] = d.y;
-        q.d[2] = d.z;
-        q.far_t = __builtin_inff();
-        rays[idx] = q;
         PathInfo pi;
-        pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
-        // radiance index: sample-major over the pass's pixel slots (see accumulate_kernel)
-        pi.slot = sidx * (ps.num_slots / ps.samples_per_pass) + slot / ps.samples_per_pass;
-        pi.pixel = pixel;
-        pi.sample = gs;
-        pi.bounces = 0;
-        pi.pad = 0;
+        if (!primary_path(cam, ps, slot, q, pi)) continue;
+        const unsigned idx = pos[0][it];
+        rays[idx] = q;
         infos[idx] = pi;
     }
 }
@@ -1450,8 +1472,15 @@ __device__ __forceinline__ void shade_one(const ShadeArgs &a, unsigned i, unsign
     if (i >= n) return;
     const unsigned id = a.hit_ids[i];
     if (id == 0xFFFFFFFFu) return; // a miss contributes nothing and ends the path (integrate_stream.rs:105)
-    const QRay ray = a.rays_in[i];
-    const PathInfo info = a.infos_in[i];
+    QRay ray;
+    PathInfo info;
+    if (a.primary) { // depth 0 without queues: slot i is its own path
+        if (!primary_path(a.cam, a.ps, i, ray, info)) return;
+        ray.far_t = a.hit_t[i];
+    } else {
+        ray = a.rays_in[i];
+        info = a.infos_in[i];
+    }
     const V3 org = v3(ray.o[0], ray.o[1], ray.o[2]);
     const V3 d = v3(ray.d[0], ray.d[1], ray.d[2]);
     const V3 hp = org + scale(d, ray.far_t); // src/ray.rs:40-42
@@ -1521,7 +1550,7 @@ constexpr int kShadeItems = 2;
 __global__ __launch_bounds__(kShadeBlock) void shade_kernel(ShadeArgs a)
 {
     __shared__ unsigned lds[64];
-    const unsigned n = *a.n_in;
+    const unsigned n = a.n_in ? *a.n_in : a.n_in_val;
     const unsigned block_base = blockIdx.x * (unsigned)(kShadeBlock * kShadeItems);
     if (block_base >= n) return; // whole block past the queue (uniform)
     bool pred[2][kShadeItems];
@@ -1546,6 +1575,43 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(ShadeArgs a)
         }
     }
 }
+
+// Depth-0 extend without a ray queue: the lane makes the camera ray of its slot itself and
+// leaves hit id and distance per slot; shade_kernel rebuilds ray and PathInfo from the slot in
+// the same way.  A slot outside the image gets a NaN direction, which the fetch retires as a miss.
+struct PrimaryIO {
+    CameraDev cam;
+    PassDev ps;
+    unsigned *hit_ids;
+    float *hit_t;
+    __device__ __forceinline__ RayRegs load(unsigned slot) const
+    {
+        QRay q;
+        PathInfo pi;
+        RayRegs r;
+        if (!primary_path(cam, ps, slot, q, pi)) {
+            const float nan = __builtin_nanf("");
+            r.o = v3(0.f, 0.f, 0.f);
+            r.d = v3(nan, nan, nan);
+            r.rd = v3(nan, nan, nan);
+            r.near_t = 0.f;
+            r.far_t = __builtin_inff();
+            return r;
+        }
+        r.o = v3(q.o[0], q.o[1], q.o[2]);
+        r.near_t = q.near_t;
+        r.d = v3(q.d[0], q.d[1], q.d[2]);
+        r.far_t = q.far_t;
+        r.rd = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z); // src/ray.rs:18
+        return r;
+    }
+    template <bool ANYHIT>
+    __device__ __forceinline__ void store(const LaneState &s) const
+    {
+        hit_ids[s.index] = s.hit;
+        hit_t[s.index] = s.r.far_t;
+    }
+};
 
 // ------------------------------------------------------------------------
 // accumulate: per pixel, sum the pass's k sample slots in a fixed order and
@@ -1684,6 +1750,40 @@ void launch_connect(bool stats, const SceneDev &sc, const QRay *rays, const Shad
 {
     QueueIO io{const_cast<QRay *>(rays), nullptr, infos, rad_r, rad_g, rad_b};
     launch_trace(true, stats, sc, io, n_ptr, 0u, n_upper, tl, max_blocks, stream);
+}
+
+void launch_extend_primary(const SceneDev &sc, const CameraDev &cam, const PassDev &ps, unsigned *hit_ids,
+                           float *hit_t, const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream)
+{
+    const PrimaryIO io{cam, ps, hit_ids, hit_t};
+    const unsigned n = ps.num_slots;
+    const unsigned grid = trace_grid(n, max_blocks);
+    const unsigned mode = (tl.mode >= 2 && !sc.wnodes) ? 1u : tl.mode;
+    switch (mode) {
+    case 0:
+        hipLaunchKernelGGL((trace_kernel<false, false, 0, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                           nullptr, n, tl);
+        break;
+    case 1:
+        hipLaunchKernelGGL((trace_kernel<false, false, 1, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                           nullptr, n, tl);
+        break;
+    case 2:
+        hipLaunchKernelGGL((trace_kernel<false, false, 2, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                           nullptr, n, tl);
+        break;
+    default:
+        hipLaunchKernelGGL((trace_kernel<false, false, 3, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
+                           nullptr, n, tl);
+        break;
+    }
+}
+
+__global__ void set_count_kernel(unsigned *dst, unsigned value) { *dst = value; }
+
+void launch_set_count(unsigned *dst, unsigned value, hipStream_t stream)
+{
+    hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(1), 0, stream, dst, value);
 }
 
 void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream)

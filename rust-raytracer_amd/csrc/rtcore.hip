@@ -86,7 +86,7 @@ struct TimedLaunch {
 };
 
 struct Workspace {
-    DevBuf rays[2], infos[2], hit_ids, shadow_rays, shadow_infos, rad, counters;
+    DevBuf rays[2], infos[2], hit_ids, hit_t, shadow_rays, shadow_infos, rad, counters;
     DevBuf keys[2], keys_sorted, perm[2], sort_temp; // [0] bounce queue, [1] shadow queue
     uint64_t paths = 0;
 };
@@ -114,6 +114,9 @@ struct rt_ctx {
     // the stream entry points are the reference's Bvh::intersect_stream / occluded_stream
     // boundary and walk the reference's binary tree unless told otherwise
     unsigned trav_stream = 1;
+    // depth 0 of rt_render without ray and PathInfo queues: extend makes the camera rays itself and
+    // shade rebuilds them from the slot (off when visit counters are requested)
+    unsigned fuse_primary = 1;
     // queues are reordered by the Morton code of the ray origin from these depths
     // on (depth of the launch that consumes the queue); 0xFFFFFFFF = never
     unsigned sort_from_depth[2] = {2, 1}; // [0] extend, [1] connect
@@ -235,6 +238,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
         int v = atoi(env);
         if (v >= 0 && v <= 3) ctx->trav_mode[0] = ctx->trav_mode[1] = (unsigned)v;
     }
+    if (const char *env = getenv("RTCORE_FUSE_PRIMARY")) ctx->fuse_primary = atoi(env) ? 1u : 0u;
     if (const char *env = getenv("RTCORE_TRAVERSAL_STREAM")) {
         int v = atoi(env);
         if (v >= 0 && v <= 3) ctx->trav_stream = (unsigned)v;
@@ -305,7 +309,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     ctx->io_b.release();
     Workspace &w = ctx->ws;
     w.rays[0].release(); w.rays[1].release(); w.infos[0].release(); w.infos[1].release();
-    w.hit_ids.release(); w.shadow_rays.release(); w.shadow_infos.release(); w.rad.release();
+    w.hit_ids.release(); w.hit_t.release(); w.shadow_rays.release(); w.shadow_infos.release(); w.rad.release();
     w.counters.release();
     w.keys[0].release(); w.keys[1].release(); w.keys_sorted.release();
     w.perm[0].release(); w.perm[1].release(); w.sort_temp.release();
@@ -331,6 +335,8 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->coop_steps = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
     } else if (n == "min_active" && in(1, 64)) {
         ctx->min_active[0] = ctx->min_active[1] = (unsigned)value;
+    } else if (n == "fuse_primary" && in(0, 1)) {
+        ctx->fuse_primary = (unsigned)value;
     } else if (n == "traversal_stream" && in(0, 3)) {
         ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
@@ -993,6 +999,7 @@ static int ensure_workspace(rt_ctx *ctx, uint64_t paths, uint32_t ncounters, boo
     for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.rays[i].ensure(paths * sizeof(QRay));
     for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.infos[i].ensure(paths * sizeof(PathInfo));
     if (rc == RT_OK) rc = w.hit_ids.ensure(paths * sizeof(uint32_t));
+    if (rc == RT_OK) rc = w.hit_t.ensure(paths * sizeof(float));
     if (rc == RT_OK) rc = w.shadow_rays.ensure(paths * sizeof(QRay));
     if (rc == RT_OK) rc = w.shadow_infos.ensure(paths * sizeof(ShadowInfo));
     if (rc == RT_OK) rc = w.rad.ensure(paths * 3 * sizeof(float));
@@ -1117,10 +1124,24 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             size_t slot;
             const unsigned *perm_extend = nullptr; // order of the ray queue about to be extended
             unsigned perm_extend_n = 0;
+            const bool fused = ctx->fuse_primary && !visit;
             rc = timed_begin(ctx, 2, s, &slot);
             if (rc != RT_OK) return rc;
-            launch_generate(cam, ps, (QRay *)w.rays[cur].p, (PathInfo *)w.infos[cur].p, &n_ray[0], rad_r, rad_g,
-                            rad_b, s);
+            if (fused) {
+                // no generate pass: the radiance slots are cleared and the number of primary rays
+                // (slots inside the image) is known on the host
+                HIP_TRY(hipMemsetAsync(rad_r, 0, (size_t)slots * 3 * sizeof(float), s));
+                uint64_t valid_px = 0;
+                for (uint32_t t = 0; t < tcount; t++) {
+                    const uint64_t tile = params->shard_index + (uint64_t)(tile0 + t) * shard_count;
+                    const uint32_t tx = (uint32_t)(tile % tiles_x), ty = (uint32_t)(tile / tiles_x);
+                    valid_px += (uint64_t)std::min(ts, params->width - tx * ts) * std::min(ts, params->height - ty * ts);
+                }
+                launch_set_count(&n_ray[0], (unsigned)(valid_px * ps.samples_this_pass), s);
+            } else {
+                launch_generate(cam, ps, (QRay *)w.rays[cur].p, (PathInfo *)w.infos[cur].p, &n_ray[0], rad_r, rad_g,
+                                rad_b, s);
+            }
             rc = timed_end(ctx, slot, s);
             if (rc != RT_OK) return rc;
             for (uint32_t b = 0; b < nb; b++) {
@@ -1129,8 +1150,12 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0],
                                 ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, perm_extend_n, nullptr, 0, 0};
                 fill_coop(ctx, sc, tle);
-                launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
-                              ps.num_slots, tle, ctx->max_blocks, s);
+                if (fused && b == 0)
+                    launch_extend_primary(sc->dev, cam, ps, (uint32_t *)w.hit_ids.p, (float *)w.hit_t.p, tle,
+                                          ctx->max_blocks, s);
+                else
+                    launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
+                                  ps.num_slots, tle, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
                 if (want && !visit) launch_count_rays(&n_ray[b], dstats, s);
@@ -1140,6 +1165,14 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 a.infos_in = (const PathInfo *)w.infos[cur].p;
                 a.hit_ids = (const uint32_t *)w.hit_ids.p;
                 a.n_in = &n_ray[b];
+                if (fused && b == 0) {
+                    a.primary = 1;
+                    a.n_in = nullptr;
+                    a.n_in_val = ps.num_slots;
+                    a.hit_t = (const float *)w.hit_t.p;
+                    a.cam = cam;
+                    a.ps = ps;
+                }
                 a.normals = sc->dev.normals;
                 a.rays_out = (QRay *)w.rays[cur ^ 1].p;
                 a.infos_out = (PathInfo *)w.infos[cur ^ 1].p;

@@ -121,3 +121,22 @@ def test_full_size_properties(rt, ctx, scenes):
     hit = ids != rt.NO_HIT
     assert (t[hit] > 0).all() and np.isinf(t[~hit]).all()
     Sg.close()
+
+
+def test_fused_primary_is_bit_identical(rt, ctx, scenes):
+    """Depth 0 without queues (the extend launch makes the camera rays itself) against the
+    generate-kernel path: the same accumulator bit for bit, ragged image size and partial last
+    pass included."""
+    sc = scenes.load("test-mesh", n_tris=4000, seed=9)
+    Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+    try:
+        for (W, H, spp, k, b) in ((100, 57, 5, 2, 2), (64, 36, 4, 0, 0)):
+            ctx.set_option("fuse_primary", 1)
+            a1, s1 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b, samples_per_pass=k)
+            ctx.set_option("fuse_primary", 0)
+            a0, s0 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b, samples_per_pass=k)
+            assert s1["total_rays"] == s0["total_rays"]
+            assert np.array_equal(a1, a0)
+    finally:
+        ctx.set_option("fuse_primary", 1)
+    Sg.close()
