@@ -36,6 +36,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
 # vector L1: 64 B per clock per CU x 256 CUs x 2.4 GHz -- the unit the trace kernels saturate
 L1_PEAK_GBS = 64.0 * 256 * 2.4
+# fp32 vector peak: 256 CUs x 128 FMA lanes x 2 flops x 2.4 GHz
+VALU_PEAK_TFLOPS = 256 * 128 * 2 * 2.4e9 / 1e12
 
 
 def measured_counters(workload):
@@ -56,6 +58,14 @@ def extend_bytes_per_ray(st):
     record) + 64 per inner-node visit + 48 per triangle test."""
     n = max(1, st["total_rays"])
     return 48.0 + 16.0 + 64.0 * st["inner_rays"] / n + 48.0 * st["obj_intersect"] / n
+
+
+def flops_per_ray(st):
+    """Algorithmic flops per ray of the reference's binary walk: 38 per inner-node visit (12 fma,
+    12 min/max, 2 compares: src/bvh/intersect1.rs:160-181) + 46 per triangle test
+    (src/triangle_opt.rs:19-42)."""
+    n = max(1, st["total_rays"])
+    return 38.0 * st["inner_rays"] / n + 46.0 * st["obj_intersect"] / n
 
 
 def connect_bytes_per_ray(st):
@@ -252,6 +262,9 @@ def main():
                 "bvh_build_s": round(build_s, 3),
                 "rays_per_step_per_gpu": int(rays / max(1, args.steps)),
                 "mean_pixel": float(img[..., :3].sum() / max(1.0, float(img[..., 3].sum()))),
+                # the reference's other two console figures (src/main.rs:170-179)
+                "samples_per_pixel_per_s": round(frame_spp * args.steps / elapsed, 2),
+                "msamples_per_s": round(frame_spp * args.steps * W * H / 1e6 / elapsed, 2),
             },
             "roofline": {
                 "bound": "hbm",
@@ -271,6 +284,11 @@ def main():
                                       "valu_issue_busy_at_2_cycles", "active_lanes_per_valu_instruction",
                                       "l1_hit_rate", "l2_hit_rate")},
                 "bytes_per_ray": round(b_ext, 1),
+                # secondary roofline: algorithmic fp32 work of the same walk against the vector ALUs
+                "flops_per_ray": round(flops_per_ray(ext_st), 1),
+                "achieved_tflops": round(flops_per_ray(ext_st) * ext_rays_per_launch / (ext_avg_ms * 1e-3) / 1e12, 2)
+                if ext_avg_ms > 0 else 0.0,
+                "valu_peak_tflops": round(VALU_PEAK_TFLOPS, 1),
                 "rays_per_launch": int(ext_rays_per_launch),
                 "avg_launch_ms": round(ext_avg_ms, 4),
                 "launches": launches["extend"],
