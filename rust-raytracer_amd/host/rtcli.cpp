@@ -1,7 +1,10 @@
 // Command-line host of the MI355X ray-tracing core: the reference's main()
 // (src/main.rs:100-189) and argument set (src/args.rs:19-44) over librtcore's C
-// ABI.  Scene definitions are the reference's (src/scene.rs:94-129); any other
-// OBJ file can be given with its own camera and light.
+// ABI.  The asian-dragon and san-miguel scene definitions are the reference's
+// (src/scene.rs:94-129); cornell-box and sponza name the other two assets the
+// reference ships (scenes/CornellBox, scenes/sponza) with a camera and light of
+// this host's own choosing, since the reference defines none for them.  Any
+// other OBJ file can be given with its own camera and light.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -34,6 +37,10 @@ struct Args {
     bool exact = false, visit_stats = false, load_only = false;
     std::string output;
     uint32_t samples_per_pass = 0;
+    std::string checkpoint;      // accumulation buffer saved after every pass
+    bool resume = false;         // continue from --checkpoint when it matches this frame
+    bool preview = false;        // rewrite the output image after every pass
+    uint32_t stop_after = 0;     // stop once this many samples/px are done (0 = all): for testing --resume
     bool have_camera = false, have_light = false;
     rt_camera camera{};
     float light_pos[3] = {0, 0, 0}, light_power = 1.f;
@@ -45,7 +52,7 @@ const char *kModes[] = {"stream", "stream-shadow-immediate", "stream-camera-only
 void usage()
 {
     puts("Usage: rtcli [OPTIONS]\n"
-         "  -s, --scene <asian-dragon|san-miguel|FILE.obj>   [default: san-miguel]\n"
+         "  -s, --scene <asian-dragon|san-miguel|cornell-box|sponza|FILE.obj>   [default: san-miguel]\n"
          "  -n, --samples <N>            [default: 128]\n"
          "  -b, --max-bounces <N>        [default: 2]\n"
          "  -t, --tile-size <N>          [default: 16]\n"
@@ -63,8 +70,15 @@ void usage()
          "      --samples-per-pass <N>   [default: as many as fit the path workspace]\n"
          "      --output <FILE.png|FILE.ppm>   [default: output/YYYYmmdd_HHMMSS.png]\n"
          "      --load-only              load the scene, build the tree on the host, print its statistics\n"
+         "      --checkpoint <FILE>      save the float4 accumulation buffer after every pass (implies passes\n"
+         "                               of --samples-per-pass samples, default 8)\n"
+         "      --resume                 continue from --checkpoint if it holds the same frame (size, seed,\n"
+         "                               bounces); the finished image is the one an uninterrupted run gives\n"
+         "      --preview                rewrite the output image after every pass\n"
+         "      --stop-after <N>         stop when N samples/px are done\n"
          "  for FILE.obj scenes: --eye x,y,z --target x,y,z --up x,y,z --fov DEG\n"
-         "                       --light-pos x,y,z --light-power P --transform <identity|asian-dragon|san-miguel>");
+         "                       --light-pos x,y,z --light-power P\n"
+         "                       --transform <identity|asian-dragon|san-miguel|cornell-box|sponza>");
 }
 
 bool parse3(const char *s, float out[3]) { return sscanf(s, "%f,%f,%f", &out[0], &out[1], &out[2]) == 3; }
@@ -141,6 +155,16 @@ bool parse_args(int argc, char **argv, Args &a)
         } else if (o == "--output") {
             if (!(v = need(i))) return false;
             a.output = v;
+        } else if (o == "--checkpoint") {
+            if (!(v = need(i))) return false;
+            a.checkpoint = v;
+        } else if (o == "--resume") {
+            a.resume = true;
+        } else if (o == "--preview") {
+            a.preview = true;
+        } else if (o == "--stop-after") {
+            if (!(v = need(i))) return false;
+            a.stop_after = (uint32_t)strtoul(v, nullptr, 10);
         } else if (o == "--eye") {
             if (!(v = need(i)) || !parse3(v, a.camera.eye)) return false;
             eye = true;
@@ -167,6 +191,10 @@ bool parse_args(int argc, char **argv, Args &a)
         }
     }
     a.have_camera = eye && target;
+    if (a.resume && a.checkpoint.empty()) {
+        fprintf(stderr, "error: --resume needs --checkpoint <FILE>\n");
+        return false;
+    }
     if (a.samples == 0 || a.tile_size == 0 || a.width < 2 || a.height < 2) {
         fprintf(stderr, "error: samples, tile size and image size must be positive (image at least 2x2)\n");
         return false;
@@ -187,7 +215,12 @@ void set_transform(const std::string &name, float m[9])
     // rows of the matrices of src/scene.rs:97-102 and 113-118 (built from columns, then transposed)
     const float dragon[9] = {1.f / 1000.f, 0, 0, 0, 0, 1.f / 1000.f, 0, 1.f / 1000.f, 0};
     const float miguel[9] = {1, 0, 0, 0, 0, -1, 0, 1, 0};
-    memcpy(m, name == "asian-dragon" ? dragon : name == "san-miguel" ? miguel : id, sizeof id);
+    // Y-up assets turned Z-up like San Miguel; Sponza is modelled in centimetres
+    const float sponza[9] = {0.01f, 0, 0, 0, 0, -0.01f, 0, 0.01f, 0};
+    const float *pick = name == "asian-dragon" ? dragon
+                        : (name == "san-miguel" || name == "cornell-box") ? miguel
+                        : name == "sponza" ? sponza : id;
+    memcpy(m, pick, sizeof id);
 }
 
 bool scene_definition(const Args &a, SceneDef &d)
@@ -204,6 +237,16 @@ bool scene_definition(const Args &a, SceneDef &d)
         set_transform("san-miguel", d.transform);
         d.camera = rt_camera{{28.f, -1.65f, 1.8f}, {27.f, -1.65f, 1.8f}, {0.f, 0.f, 1.f}, 60.f};
         d.light = rt_light{{20.f, -2.5f, 3.f}, {20.f, 20.f, 20.f}};
+    } else if (a.scene == "cornell-box") { // no definition in the reference: camera and light chosen here
+        d.obj_path = "./scenes/CornellBox/CornellBox-Original.obj";
+        set_transform("cornell-box", d.transform);
+        d.camera = rt_camera{{0.f, -3.2f, 0.8f}, {0.f, 0.f, 0.8f}, {0.f, 0.f, 1.f}, 40.f};
+        d.light = rt_light{{0.f, 0.f, 1.4f}, {3.f, 3.f, 3.f}};
+    } else if (a.scene == "sponza") { // no definition in the reference: camera and light chosen here
+        d.obj_path = "./scenes/sponza/sponza.obj";
+        set_transform("sponza", d.transform);
+        d.camera = rt_camera{{-12.f, 0.5f, 2.5f}, {0.f, 0.f, 3.f}, {0.f, 0.f, 1.f}, 60.f};
+        d.light = rt_light{{0.f, 0.f, 12.f}, {600.f, 600.f, 600.f}};
     } else {
         d.obj_path = a.scene;
         set_transform(a.transform, d.transform);
@@ -233,6 +276,42 @@ std::string fmt_duration(double s)
     else
         snprintf(b, sizeof b, "%.2fµs", s * 1e6);
     return b;
+}
+
+// Checkpoint of a frame in progress: the float4 accumulation buffer (sums of r, g, b and of sample
+// counts, src/main.rs:108) with the frame parameters the sums depend on.  Random numbers are keyed by
+// (seed, pixel, sample), so continuing at `samples_done` gives the frame an uninterrupted run gives.
+struct CheckpointHeader {
+    char magic[8]; // "RTACCUM1"
+    uint32_t width, height, samples_done, max_bounces, tile_size, reserved;
+    uint64_t seed;
+};
+
+bool write_checkpoint(const std::string &path, const CheckpointHeader &h, const std::vector<float> &accum)
+{
+    const std::string tmp = path + ".tmp"; // rename is atomic: a killed run never leaves half a file
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(accum.data(), sizeof(float), accum.size(), f) == accum.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok && rename(tmp.c_str(), path.c_str()) == 0;
+}
+
+// 1 = loaded, 0 = no file, -1 = a file that does not belong to this frame
+int read_checkpoint(const std::string &path, const CheckpointHeader &want, std::vector<float> &accum, uint32_t &samples_done)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return 0;
+    CheckpointHeader h{};
+    std::vector<float> data(accum.size());
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, want.magic, 8) == 0 && h.width == want.width &&
+              h.height == want.height && h.max_bounces == want.max_bounces && h.tile_size == want.tile_size &&
+              h.seed == want.seed && fread(data.data(), sizeof(float), data.size(), f) == data.size();
+    fclose(f);
+    if (!ok) return -1;
+    accum.swap(data);
+    samples_done = h.samples_done;
+    return 1;
 }
 
 int fail_rt(const char *what)
@@ -313,14 +392,53 @@ int main(int argc, char **argv)
 
     std::vector<float> accum((size_t)args.width * args.height * 4, 0.f);
     rt_trace_stats stats{};
+    CheckpointHeader ck{{'R', 'T', 'A', 'C', 'C', 'U', 'M', '1'}, args.width, args.height, 0, args.max_bounces,
+                        args.tile_size, 0, args.seed};
+    uint32_t start = 0;
+    if (args.resume) {
+        const int r = read_checkpoint(args.checkpoint, ck, accum, start);
+        if (r < 0) {
+            fprintf(stderr, "error: %s is not a checkpoint of this frame (size, bounces, tile size or seed differ)\n",
+                    args.checkpoint.c_str());
+            return 1;
+        }
+        if (r > 0) printf("resumed %s at %u/%u samples\n", args.checkpoint.c_str(), start, args.samples);
+    }
+    std::string out = args.output;
+    if (out.empty()) { // src/main.rs:184-188
+        mkdir("output", 0777);
+        char name[64];
+        time_t now = time(nullptr);
+        strftime(name, sizeof name, "output/%Y%m%d_%H%M%S.png", localtime(&now));
+        out = name;
+    }
+    std::vector<uint8_t> rgb((size_t)args.width * args.height * 3);
+    auto write_image = [&]() -> bool {
+        if (rt_resolve(ctx, accum.data(), args.width, args.height, rgb.data()) != RT_OK) {
+            fail_rt("rt_resolve");
+            return false;
+        }
+        const bool ppm = out.size() > 4 && out.compare(out.size() - 4, 4, ".ppm") == 0;
+        if (!(ppm ? host::write_ppm(out, rgb.data(), args.width, args.height)
+                  : host::write_png(out, rgb.data(), args.width, args.height))) {
+            fprintf(stderr, "error: cannot write %s\n", out.c_str());
+            return false;
+        }
+        return true;
+    };
+
     auto t_render = std::chrono::steady_clock::now();
-    // one call per frame; with --progress one call per pass of the frame's samples
-    const uint32_t chunk = args.progress ? (args.samples_per_pass ? args.samples_per_pass : 8u) : args.samples;
-    for (uint32_t s0 = 0; s0 < args.samples; s0 += chunk) {
+    // one call per frame; with --progress, --checkpoint or --preview one call per pass of the frame's samples
+    const bool passes = args.progress || args.preview || !args.checkpoint.empty();
+    const uint32_t chunk = passes ? (args.samples_per_pass ? args.samples_per_pass : 8u) : args.samples;
+    const uint32_t end = args.stop_after ? std::min(args.stop_after, args.samples) : args.samples;
+    const uint32_t first = std::min(start, args.samples);
+    uint32_t done = first;
+    for (uint32_t s0 = first; s0 < end; s0 += chunk) {
         rt_render_params p{};
         p.width = args.width;
         p.height = args.height;
-        p.samples = std::min(chunk, args.samples - s0);
+        p.samples = std::min(chunk, end - s0);
         p.sample_offset = s0;
         p.max_bounces = args.max_bounces;
         p.tile_size = args.tile_size;
@@ -330,7 +448,16 @@ int main(int argc, char **argv)
         p.flags = args.visit_stats ? RT_RENDER_VISIT_STATS : 0;
         p.seed = args.seed;
         if (rt_render(scene, &def.camera, &def.light, &p, accum.data(), &stats) != RT_OK) return fail_rt("rt_render");
-        if (args.progress) printf("%u/%u samples completed\n", s0 + p.samples, args.samples);
+        done = s0 + p.samples;
+        if (args.progress) printf("%u/%u samples completed\n", done, args.samples);
+        if (!args.checkpoint.empty()) {
+            ck.samples_done = done;
+            if (!write_checkpoint(args.checkpoint, ck, accum)) {
+                fprintf(stderr, "error: cannot write %s\n", args.checkpoint.c_str());
+                return 1;
+            }
+        }
+        if (args.preview && done < end && !write_image()) return 1;
     }
     const double elapsed = seconds_since(t_render);
 
@@ -349,28 +476,14 @@ int main(int argc, char **argv)
     } else {
         printf("per-visit counters not collected (--visit-stats)\n");
     }
-    // src/main.rs:170-179
+    // src/main.rs:170-179, over the samples this run rendered
+    const uint32_t rendered = done - first;
     printf("%s for %u samples/px, %.2f samples/px/sec, %.2f MRays/sec, %.2f MSamples/sec\n",
-           fmt_duration(elapsed).c_str(), args.samples, (float)args.samples / (float)elapsed,
+           fmt_duration(elapsed).c_str(), rendered, (float)rendered / (float)elapsed,
            (float)stats.total_rays / 1000000.f / (float)elapsed,
-           (float)((double)args.width * args.height * args.samples) / 1000000.f / (float)elapsed);
+           (float)((double)args.width * args.height * rendered) / 1000000.f / (float)elapsed);
 
-    std::vector<uint8_t> rgb((size_t)args.width * args.height * 3);
-    if (rt_resolve(ctx, accum.data(), args.width, args.height, rgb.data()) != RT_OK) return fail_rt("rt_resolve");
-    std::string out = args.output;
-    if (out.empty()) { // src/main.rs:184-188
-        mkdir("output", 0777);
-        char name[64];
-        time_t now = time(nullptr);
-        strftime(name, sizeof name, "output/%Y%m%d_%H%M%S.png", localtime(&now));
-        out = name;
-    }
-    const bool ppm = out.size() > 4 && out.compare(out.size() - 4, 4, ".ppm") == 0;
-    if (!(ppm ? host::write_ppm(out, rgb.data(), args.width, args.height)
-              : host::write_png(out, rgb.data(), args.width, args.height))) {
-        fprintf(stderr, "error: cannot write %s\n", out.c_str());
-        return 1;
-    }
+    if (!write_image()) return 1;
     printf("wrote %s\n", out.c_str());
     rt_scene_destroy(scene);
     rt_ctx_destroy(ctx);

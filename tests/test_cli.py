@@ -64,6 +64,13 @@ def test_argument_errors(tmp_path):
     assert run("--frobnicate").returncode == 2
     missing = run("--scene", str(tmp_path / "nope.obj"), "--load-only")
     assert missing.returncode == 1 and "cannot open" in missing.stderr
+    assert run("--resume").returncode == 2                      # needs --checkpoint
+    for name, path in (("cornell-box", "./scenes/CornellBox/CornellBox-Original.obj"),
+                       ("sponza", "./scenes/sponza/sponza.obj"),
+                       ("asian-dragon", "./scenes/asian_dragon_obj/asian_dragon.obj"),
+                       ("san-miguel", "./scenes/San_Miguel/san-miguel.obj")):
+        out = subprocess.run([CLI, "-s", name, "--load-only"], capture_output=True, text=True, cwd=str(tmp_path))
+        assert out.returncode == 1 and ("cannot open " + path) in out.stderr   # the assets are not shipped
     helped = run("--help")
     assert helped.returncode == 0 and "--max-bounces" in helped.stdout and "--tile-size" in helped.stdout
 
@@ -131,3 +138,32 @@ def test_cli_frame_is_the_library_frame(rt, scenes, tmp_path):
     assert np.array_equal(read_png_rgb8(png), ctx.resolve(acc2))
     Sg.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_cli_checkpoint_resume_gives_the_uninterrupted_frame(scenes, tmp_path):
+    sc = scenes.load("cornell-class")
+    path = str(tmp_path / "scene.obj")
+    scenes.write_obj(sc, path)
+    cam, light = sc.camera, sc.light
+    common = ["--scene", path, "-n", "6", "-b", "2", "--width", "80", "--height", "48", "--samples-per-pass", "2",
+              "--eye", "%r,%r,%r" % tuple(float(x) for x in cam.eye),
+              "--target", "%r,%r,%r" % tuple(float(x) for x in cam.target),
+              "--up", "%r,%r,%r" % tuple(float(x) for x in cam.up), "--fov", repr(float(cam.fov_deg)),
+              "--light-pos", "%r,%r,%r" % tuple(float(x) for x in light.pos),
+              "--light-power", repr(float(light.intensity[0]))]
+    whole, part, ck = str(tmp_path / "whole.ppm"), str(tmp_path / "part.ppm"), str(tmp_path / "frame.ck")
+    assert run(*common, "--output", whole).returncode == 0
+    first = run(*common, "--output", part, "--checkpoint", ck, "--stop-after", "4", "--preview")
+    assert first.returncode == 0, first.stderr
+    assert os.path.getsize(ck) == 40 + 80 * 48 * 16
+    assert not np.array_equal(read_ppm(part), read_ppm(whole))          # 4 of 6 samples
+    other_seed = run(*common, "--output", part, "--checkpoint", ck, "--resume", "--seed", "7")
+    assert other_seed.returncode == 1 and "not a checkpoint of this frame" in other_seed.stderr
+    second = run(*common, "--output", part, "--checkpoint", ck, "--resume", "--progress")
+    assert second.returncode == 0, second.stderr
+    assert "resumed %s at 4/6 samples" % ck in second.stdout and "6/6 samples completed" in second.stdout
+    assert "for 2 samples/px" in second.stdout
+    assert np.array_equal(read_ppm(part), read_ppm(whole))
+    again = run(*common, "--output", part, "--checkpoint", ck, "--resume")   # nothing left to render
+    assert again.returncode == 0 and np.array_equal(read_ppm(part), read_ppm(whole))
