@@ -30,4 +30,14 @@ struct Mesh {
 // face refers to a missing element.
 bool load_obj(const std::string &path, const float transform[9], Mesh &out, std::string &error);
 
+// The same mesh -- every array equal element for element, the same error for the same file -- built
+// by `threads` threads (0 = up to 16): chunked parsing, then vertex sharing split by key hash with
+// vertices numbered in order of first appearance (obj_loader_mt.cpp).  For the reference's
+// gigabyte-sized scene files.  A thread gets at least min_chunk_bytes of text.
+bool load_obj_parallel(const std::string &path, const float transform[9], unsigned threads, Mesh &out,
+                       std::string &error, size_t min_chunk_bytes = 65536);
+
+// FNV-1a over the five arrays of a mesh: equal meshes, equal fingerprints
+uint64_t mesh_fingerprint(const Mesh &m);
+
 } // namespace host

@@ -40,6 +40,9 @@ struct Args {
     std::string checkpoint;      // accumulation buffer saved after every pass
     bool resume = false;         // continue from --checkpoint when it matches this frame
     bool preview = false;        // rewrite the output image after every pass
+    std::string loader = "parallel"; // OBJ loader: parallel (default) or serial, same mesh
+    unsigned threads = 0;            // loader threads, 0 = up to 16
+    size_t loader_chunk = 65536;     // least text per loader thread
     uint32_t stop_after = 0;     // stop once this many samples/px are done (0 = all): for testing --resume
     bool have_camera = false, have_light = false;
     rt_camera camera{};
@@ -76,6 +79,8 @@ void usage()
          "                               bounces); the finished image is the one an uninterrupted run gives\n"
          "      --preview                rewrite the output image after every pass\n"
          "      --stop-after <N>         stop when N samples/px are done\n"
+         "      --loader <parallel|serial>   OBJ loader; both give the same mesh [default: parallel]\n"
+         "      --threads <N>            threads of the parallel loader [default: up to 16]\n"
          "  for FILE.obj scenes: --eye x,y,z --target x,y,z --up x,y,z --fov DEG\n"
          "                       --light-pos x,y,z --light-power P\n"
          "                       --transform <identity|asian-dragon|san-miguel|cornell-box|sponza>");
@@ -158,6 +163,19 @@ bool parse_args(int argc, char **argv, Args &a)
         } else if (o == "--checkpoint") {
             if (!(v = need(i))) return false;
             a.checkpoint = v;
+        } else if (o == "--loader") {
+            if (!(v = need(i))) return false;
+            a.loader = v;
+            if (a.loader != "parallel" && a.loader != "serial") {
+                fprintf(stderr, "error: invalid value '%s' for '--loader'\n", v);
+                return false;
+            }
+        } else if (o == "--threads") {
+            if (!(v = need(i))) return false;
+            a.threads = (unsigned)strtoul(v, nullptr, 10);
+        } else if (o == "--loader-chunk-bytes") { // testing: cut small files into many chunks
+            if (!(v = need(i))) return false;
+            a.loader_chunk = (size_t)strtoull(v, nullptr, 10);
         } else if (o == "--resume") {
             a.resume = true;
         } else if (o == "--preview") {
@@ -336,7 +354,10 @@ int main(int argc, char **argv)
     auto t_load = std::chrono::steady_clock::now();
     host::Mesh mesh;
     std::string error;
-    if (!host::load_obj(def.obj_path, def.transform, mesh, error)) {
+    const bool loaded = args.loader == "serial" ? host::load_obj(def.obj_path, def.transform, mesh, error)
+                                                : host::load_obj_parallel(def.obj_path, def.transform, args.threads, mesh, error,
+                                                                          args.loader_chunk);
+    if (!loaded) {
         fprintf(stderr, "error: %s\n", error.c_str());
         return 1;
     }
@@ -361,6 +382,7 @@ int main(int argc, char **argv)
                st.max_depth, st.max_objs);
         printf("bvh build %s\n", fmt_duration(seconds_since(t_bvh)).c_str());
         printf("%u vertices, %u inner nodes\n", mesh.num_vertices(), info.num_inner_nodes);
+        printf("mesh fingerprint %016llx\n", (unsigned long long)host::mesh_fingerprint(mesh));
         return 0;
     }
 

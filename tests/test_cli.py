@@ -167,3 +167,92 @@ def test_cli_checkpoint_resume_gives_the_uninterrupted_frame(scenes, tmp_path):
     assert np.array_equal(read_ppm(part), read_ppm(whole))
     again = run(*common, "--output", part, "--checkpoint", ck, "--resume")   # nothing left to render
     assert again.returncode == 0 and np.array_equal(read_ppm(part), read_ppm(whole))
+
+
+def load_only(path, *extra):
+    out = run("--scene", path, "--load-only", *extra)
+    lines = [l for l in out.stdout.splitlines() if not l.startswith("loaded ") and not l.startswith("bvh build")]
+    return out.returncode, lines, out.stderr.strip()
+
+
+def tricky_obj(rng, n_faces):
+    """An OBJ text with everything the loaders have to agree on: comments, blank and CRLF lines,
+    leading blanks, polygons, relative references that reach far back, faces without vt / vn,
+    shared and repeated vertices, degenerate faces, exponent and long-mantissa numbers."""
+    out = ["# generated\r", "", "o thing", "g part"]
+    nv = nt = nn = 0
+    for i in range(n_faces):
+        k = int(rng.integers(3, 6))
+        base = rng.normal(size=3) * 10
+        for j in range(k):
+            p = base + rng.normal(size=3)
+            style = int(rng.integers(0, 4))
+            if style == 0:
+                out.append("v %.6f %.6f %.6f" % tuple(p))
+            elif style == 1:
+                out.append("  v\t%.9e %.3f %.17g\r" % tuple(p))
+            elif style == 2:
+                out.append("v %d %d %d" % tuple(np.round(p)))
+            else:
+                out.append("v %.8f %.8f %.8f 1.0" % tuple(p))
+            nv += 1
+        if rng.random() < 0.7:
+            out.append("vt %.4f %.4f" % tuple(rng.random(2)))
+            nt += 1
+        if rng.random() < 0.7:
+            n = rng.normal(size=3)
+            out.append("vn %.5f %.5f %.5f" % tuple(n / np.linalg.norm(n)))
+            nn += 1
+        kind = int(rng.integers(0, 5))
+        if kind == 0:    # relative references
+            out.append("f " + " ".join("%d" % (-(k - j)) for j in range(k)))
+        elif kind == 1 and nt and nn:
+            out.append("f " + " ".join("%d/%d/%d" % (nv - k + j + 1, nt, nn) for j in range(k)) + " \r")
+        elif kind == 2 and nn:
+            out.append("f " + " ".join("%d//-1" % (nv - k + j + 1) for j in range(k)))
+        elif kind == 3:  # reaches back to early vertices, repeats one (degenerate triangle in the fan)
+            a = int(rng.integers(1, nv + 1))
+            out.append("f %d %d %d %d" % (a, nv, nv, nv - 1))
+        else:
+            out.append("\tf " + " ".join("%d" % (nv - k + j + 1) for j in range(k)))
+        if rng.random() < 0.1:
+            out.append("usemtl m%d" % i)
+    return "\n".join(out) + ("\n" if rng.random() < 0.5 else "")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_parallel_loader_gives_the_serial_mesh(tmp_path, seed):
+    rng = np.random.default_rng(seed)
+    path = str(tmp_path / "tricky.obj")
+    with open(path, "w", newline="") as f:
+        f.write(tricky_obj(rng, 400))
+    rc, want, err = load_only(path, "--loader", "serial")
+    assert rc == 0, err
+    assert any(l.startswith("mesh fingerprint ") for l in want)
+    for threads, chunk in ((1, 65536), (2, 4096), (5, 1000), (16, 64), (64, 1)):
+        rc, got, err = load_only(path, "--loader", "parallel", "--threads", str(threads),
+                                 "--loader-chunk-bytes", str(chunk))
+        assert rc == 0, err
+        assert got == want, (threads, chunk)
+
+
+@pytest.mark.parametrize("bad,msg", [("f 1 2 999999\n", "bad face reference on line"),
+                                     ("f 1 2\n", "face with fewer than 3 vertices on line"),
+                                     ("f 1 2 -999999\n", "bad face reference on line"),
+                                     ("f 1/2/3/4 2 3\n", "bad face reference on line"),
+                                     ("f 1 x 3\n", "bad face reference on line")])
+def test_parallel_loader_reports_the_serial_error(tmp_path, bad, msg):
+    rng = np.random.default_rng(7)
+    text = tricky_obj(rng, 120)
+    lines = text.split("\n")
+    lines.insert(len(lines) // 2, bad.rstrip("\n"))
+    lines.insert(len(lines) - 3, "f 1 2")        # a later error must not win
+    path = str(tmp_path / "bad.obj")
+    with open(path, "w", newline="") as f:
+        f.write("\n".join(lines))
+    rc, _, want = load_only(path, "--loader", "serial")
+    assert rc == 1 and msg in want
+    for threads, chunk in ((1, 65536), (7, 500), (32, 16)):
+        rc, _, got = load_only(path, "--loader", "parallel", "--threads", str(threads),
+                               "--loader-chunk-bytes", str(chunk))
+        assert rc == 1 and got == want
