@@ -266,7 +266,10 @@ int rt_bvh_refine_host(const float *positions, uint32_t num_vertices, const uint
 /* Bvh::intersect_stream, src/bvh/intersect_stream.rs:10-15: closest hit for n
  * rays.  hits[i] = mesh triangle id or RT_NO_HIT; rays[i].origin_far[3] is
  * shrunk to the hit distance.  Accept rule near <= t < far
- * (src/bvh/intersect_stream.rs:418).  stats may be NULL. */
+ * (src/bvh/intersect_stream.rs:418).  stats may be NULL.  The host variant
+ * uploads and traces in chunks of 2^20 rays (upload of the next chunk overlaps
+ * the trace of the current one) and brings back hit id and far distance only;
+ * every other byte of rays[] is left as the caller wrote it. */
 int rt_intersect_stream(rt_scene *scene, rt_stream_ray *rays, uint32_t *hits, uint32_t n,
                         rt_trace_stats *stats);
 int rt_intersect_stream_device(rt_scene *scene, rt_stream_ray *d_rays, uint32_t *d_hits,

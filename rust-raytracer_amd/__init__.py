@@ -16,6 +16,15 @@ import os
 
 import numpy as np
 
+# PyTorch wheels carry their own copy of the HIP runtime.  A process that loads librtcore.so (and with
+# it the system's libamdhip64) first and imports torch afterwards can end up with two runtimes, and
+# the second one finds no GPU ("No HIP GPUs are available").  Importing torch first makes both use the
+# same copy; hosts without torch simply use the system runtime.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTCORE_LIB selects another build of the same library (tuning experiments)
 LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(_HERE, "librtcore.so")

@@ -132,6 +132,7 @@ void launch_set_count(unsigned *dst, unsigned value, hipStream_t stream);
 void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream);
 void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,
                      float *rad_r, float *rad_g, float *rad_b, hipStream_t stream);
+void launch_gather_far(const rt_stream_ray_dev *rays, float *far_t, unsigned n, hipStream_t stream);
 void launch_generate_stream(const CameraDev &cam, const PassDev &ps, rt_stream_ray_dev *rays,
                             unsigned long long total, hipStream_t stream);
 void launch_shade(const ShadeArgs &a, unsigned n_upper, hipStream_t stream);

@@ -1779,6 +1779,19 @@ void launch_extend_primary(const SceneDev &sc, const CameraDev &cam, const PassD
     }
 }
 
+// far distances of a StreamRay array as a dense array (what a closest-hit call changes in its rays)
+__global__ __launch_bounds__(256) void gather_far_kernel(const rt_stream_ray_dev *rays, float *far_t, unsigned n)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) far_t[i] = rays[i].origin_far.w;
+}
+
+void launch_gather_far(const rt_stream_ray_dev *rays, float *far_t, unsigned n, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_far_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, rays, far_t, n);
+}
+
 __global__ void set_count_kernel(unsigned *dst, unsigned value) { *dst = value; }
 
 void launch_set_count(unsigned *dst, unsigned value, hipStream_t stream)

@@ -132,6 +132,13 @@ struct rt_ctx {
     uint64_t pending_key[3] = {0, 0, 0};
     uint64_t max_paths = 1ull << 26;
     DevBuf io_a, io_b; // staging for the host-buffer entry points
+    // rt_intersect_stream / rt_occluded_stream work through their rays in chunks: while chunk k is
+    // traced, chunk k+1 is uploaded on `copy_stream` and the results of chunk k-1 (hit ids and far
+    // distances, 8 bytes per ray instead of the 48-byte ray) are unpacked on the host
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t h2d_done[2] = {nullptr, nullptr}, kernel_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
+    DevBuf chunk_rays[2], chunk_out[2];
+    void *h_out[2] = {nullptr, nullptr}; // pinned, kHostChunk * 8 bytes each
     std::vector<TimedLaunch> pool;
     size_t used = 0;
     bool timing = true;
@@ -307,6 +314,15 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     ctx->coop.release();
     ctx->io_a.release();
     ctx->io_b.release();
+    for (int k = 0; k < 2; k++) {
+        ctx->chunk_rays[k].release();
+        ctx->chunk_out[k].release();
+        if (ctx->h_out[k]) (void)hipHostFree(ctx->h_out[k]);
+        if (ctx->h2d_done[k]) (void)hipEventDestroy(ctx->h2d_done[k]);
+        if (ctx->kernel_done[k]) (void)hipEventDestroy(ctx->kernel_done[k]);
+        if (ctx->out_done[k]) (void)hipEventDestroy(ctx->out_done[k]);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     Workspace &w = ctx->ws;
     w.rays[0].release(); w.rays[1].release(); w.infos[0].release(); w.infos[1].release();
     w.hit_ids.release(); w.hit_t.release(); w.shadow_rays.release(); w.shadow_infos.release(); w.rad.release();
@@ -816,7 +832,6 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
                                uint8_t *d_occ, uint32_t n, rt_trace_stats *stats, hipStream_t s, bool sync_stats)
 {
     rt_ctx *ctx = sc->ctx;
-    ctx->used = 0;
     bool want = stats != nullptr;
     if (want) HIP_TRY(hipMemsetAsync(ctx->dstats.p, 0, 2 * sizeof(StatsDev), s));
     size_t slot;
@@ -851,6 +866,7 @@ extern "C" int rt_intersect_stream_device(rt_scene *sc, rt_stream_ray *d_rays, u
     if (n && (!d_rays || !d_hits)) return fail(RT_ERR_INVALID, "rt_intersect_stream_device: NULL buffer");
     int rc = ctx_set_device(sc->ctx);
     if (rc != RT_OK) return rc;
+    sc->ctx->used = 0;
     return trace_stream_device(sc, false, (rt_stream_ray_dev *)d_rays, d_hits, nullptr, n, stats,
                                (hipStream_t)hip_stream, true);
 }
@@ -862,9 +878,132 @@ extern "C" int rt_occluded_stream_device(rt_scene *sc, const rt_stream_ray *d_ra
     if (n && (!d_rays || !d_occluded)) return fail(RT_ERR_INVALID, "rt_occluded_stream_device: NULL buffer");
     int rc = ctx_set_device(sc->ctx);
     if (rc != RT_OK) return rc;
+    sc->ctx->used = 0;
     return trace_stream_device(sc, true, (rt_stream_ray_dev *)d_rays, nullptr, d_occluded, n, stats,
                                (hipStream_t)hip_stream, true);
 }
+
+namespace {
+
+constexpr uint32_t kHostChunk = 1u << 20; // rays per chunk of the host-buffer entry points
+
+void add_stats(rt_trace_stats &a, const rt_trace_stats &b)
+{
+    a.total_rays += b.total_rays;
+    a.inner_visit += b.inner_visit;
+    a.inner_rays += b.inner_rays;
+    a.leaf_visit += b.leaf_visit;
+    a.leaf_rays += b.leaf_rays;
+    a.leaf_objs += b.leaf_objs;
+    a.obj_intersect += b.obj_intersect;
+}
+
+int ensure_host_pipeline(rt_ctx *ctx, uint32_t n)
+{
+    if (!ctx->copy_stream) {
+        if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(RT_ERR_HIP, "hipStreamCreate failed");
+        for (int k = 0; k < 2; k++)
+            if (hipEventCreateWithFlags(&ctx->h2d_done[k], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->kernel_done[k], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->out_done[k], hipEventDisableTiming) != hipSuccess)
+                return fail(RT_ERR_HIP, "hipEventCreate failed");
+    }
+    const size_t chunk = std::min<size_t>(n, kHostChunk);
+    const int bufs = n > kHostChunk ? 2 : 1;
+    for (int k = 0; k < bufs; k++) {
+        int rc = ctx->chunk_rays[k].ensure(chunk * sizeof(rt_stream_ray));
+        if (rc == RT_OK) rc = ctx->chunk_out[k].ensure(chunk * 8);
+        if (rc != RT_OK) return rc;
+        if (!ctx->h_out[k] && hipHostMalloc(&ctx->h_out[k], (size_t)kHostChunk * 8) != hipSuccess)
+            return fail(RT_ERR_NOMEM, "pinned host allocation failed");
+    }
+    return RT_OK;
+}
+
+// Closest-hit (hits != NULL) or any-hit (occluded != NULL) over host rays, chunk by chunk.
+int host_stream_trace(rt_scene *sc, rt_stream_ray *rays, const rt_stream_ray *rays_in, uint32_t *hits, uint8_t *occluded,
+                      uint32_t n, rt_trace_stats *stats)
+{
+    rt_ctx *ctx = sc->ctx;
+    int rc = ctx_set_device(ctx);
+    if (rc == RT_OK) rc = ensure_host_pipeline(ctx, n);
+    if (rc != RT_OK) return rc;
+    const bool anyhit = occluded != nullptr;
+    hipStream_t s = ctx->stream, cs = ctx->copy_stream;
+    const uint32_t chunks = (n + kHostChunk - 1) / kHostChunk;
+    auto count = [&](uint32_t k) { return std::min(kHostChunk, n - k * kHostChunk); };
+    const bool single = chunks == 1; // one chunk (a tile of the reference is 32,768 rays): one stream, no events
+    // Results of chunk k: pinned buffer -> the caller's arrays.  (Doing this on a helper thread beside
+    // the next upload was measured slower: both are bound by host memory bandwidth.)
+    auto scatter = [&](uint32_t k) {
+        const int b = (int)(k & 1u);
+        const uint32_t m = count(k);
+        const size_t at = (size_t)k * kHostChunk;
+        if (anyhit) {
+            memcpy(occluded + at, ctx->h_out[b], m);
+        } else {
+            const uint32_t *h = (const uint32_t *)ctx->h_out[b];
+            const float *f = (const float *)ctx->h_out[b] + m;
+            memcpy(hits + at, h, (size_t)m * sizeof(uint32_t));
+            for (uint32_t i = 0; i < m; i++) rays[at + i].origin_far[3] = f[i];
+        }
+    };
+    ctx->used = 0;
+    rt_trace_stats total{}, split[2]{};
+    uint64_t max_steps[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(ctx->chunk_rays[0].p, rays_in, (size_t)count(0) * sizeof(rt_stream_ray), hipMemcpyHostToDevice,
+                           single ? s : cs));
+    if (!single) HIP_TRY(hipEventRecord(ctx->h2d_done[0], cs));
+    for (uint32_t k = 0; k < chunks; k++) {
+        const int b = (int)(k & 1u);
+        const uint32_t m = count(k);
+        rt_stream_ray_dev *d_rays = (rt_stream_ray_dev *)ctx->chunk_rays[b].p;
+        uint32_t *d_hits = (uint32_t *)ctx->chunk_out[b].p;
+        float *d_far = (float *)ctx->chunk_out[b].p + m;
+        if (!single) HIP_TRY(hipStreamWaitEvent(s, ctx->h2d_done[b], 0));
+        rt_trace_stats st{};
+        rc = trace_stream_device(sc, anyhit, d_rays, anyhit ? nullptr : d_hits, anyhit ? (uint8_t *)d_hits : nullptr, m,
+                                 stats ? &st : nullptr, s, true);
+        if (rc != RT_OK) return rc;
+        if (stats) {
+            add_stats(total, st);
+            for (int q = 0; q < 2; q++) { // the per-kind view of the call is the sum over its chunks
+                add_stats(split[q], ctx->last_split[q]);
+                max_steps[q] = std::max(max_steps[q], ctx->last_max_steps[q]);
+            }
+        }
+        if (!anyhit) launch_gather_far(d_rays, d_far, m, s);
+        if (!single) HIP_TRY(hipEventRecord(ctx->kernel_done[b], s));
+        HIP_TRY(hipMemcpyAsync(ctx->h_out[b], ctx->chunk_out[b].p, anyhit ? (size_t)m : (size_t)m * 8, hipMemcpyDeviceToHost, s));
+        if (!single) HIP_TRY(hipEventRecord(ctx->out_done[b], s));
+        if (k + 1 < chunks) { // upload the next chunk while this one is traced
+            if (k >= 1) HIP_TRY(hipStreamWaitEvent(cs, ctx->kernel_done[b ^ 1], 0)); // its buffer was chunk k-1's
+            HIP_TRY(hipMemcpyAsync(ctx->chunk_rays[b ^ 1].p, rays_in + (size_t)(k + 1) * kHostChunk,
+                                   (size_t)count(k + 1) * sizeof(rt_stream_ray), hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipEventRecord(ctx->h2d_done[b ^ 1], cs));
+        }
+        if (k >= 1) { // chunk k-1 is back by now: unpack it while chunk k is traced
+            HIP_TRY(hipEventSynchronize(ctx->out_done[b ^ 1]));
+            scatter(k - 1);
+        }
+    }
+    if (single)
+        HIP_TRY(hipStreamSynchronize(s));
+    else
+        HIP_TRY(hipEventSynchronize(ctx->out_done[(chunks - 1) & 1u]));
+    scatter(chunks - 1);
+    if (stats) {
+        add_stats(*stats, total);
+        for (int q = 0; q < 2; q++) {
+            ctx->last_split[q] = split[q];
+            ctx->last_max_steps[q] = max_steps[q];
+        }
+    }
+    return RT_OK;
+}
+
+} // namespace
 
 extern "C" int rt_intersect_stream(rt_scene *sc, rt_stream_ray *rays, uint32_t *hits, uint32_t n,
                                    rt_trace_stats *stats)
@@ -872,21 +1011,7 @@ extern "C" int rt_intersect_stream(rt_scene *sc, rt_stream_ray *rays, uint32_t *
     if (!sc) return fail(RT_ERR_INVALID, "rt_intersect_stream: scene is NULL");
     if (n && (!rays || !hits)) return fail(RT_ERR_INVALID, "rt_intersect_stream: NULL buffer");
     if (n == 0) return RT_OK;
-    rt_ctx *ctx = sc->ctx;
-    int rc = ctx_set_device(ctx);
-    if (rc != RT_OK) return rc;
-    rc = ctx->io_a.ensure((size_t)n * sizeof(rt_stream_ray));
-    if (rc == RT_OK) rc = ctx->io_b.ensure((size_t)n * sizeof(uint32_t));
-    if (rc != RT_OK) return rc;
-    hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, rays, (size_t)n * sizeof(rt_stream_ray), hipMemcpyHostToDevice, s));
-    rc = trace_stream_device(sc, false, (rt_stream_ray_dev *)ctx->io_a.p, (uint32_t *)ctx->io_b.p, nullptr, n,
-                             stats, s, true);
-    if (rc != RT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(rays, ctx->io_a.p, (size_t)n * sizeof(rt_stream_ray), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hits, ctx->io_b.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return RT_OK;
+    return host_stream_trace(sc, rays, rays, hits, nullptr, n, stats);
 }
 
 extern "C" int rt_occluded_stream(rt_scene *sc, const rt_stream_ray *rays, uint8_t *occluded, uint32_t n,
@@ -895,20 +1020,7 @@ extern "C" int rt_occluded_stream(rt_scene *sc, const rt_stream_ray *rays, uint8
     if (!sc) return fail(RT_ERR_INVALID, "rt_occluded_stream: scene is NULL");
     if (n && (!rays || !occluded)) return fail(RT_ERR_INVALID, "rt_occluded_stream: NULL buffer");
     if (n == 0) return RT_OK;
-    rt_ctx *ctx = sc->ctx;
-    int rc = ctx_set_device(ctx);
-    if (rc != RT_OK) return rc;
-    rc = ctx->io_a.ensure((size_t)n * sizeof(rt_stream_ray));
-    if (rc == RT_OK) rc = ctx->io_b.ensure((size_t)n);
-    if (rc != RT_OK) return rc;
-    hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, rays, (size_t)n * sizeof(rt_stream_ray), hipMemcpyHostToDevice, s));
-    rc = trace_stream_device(sc, true, (rt_stream_ray_dev *)ctx->io_a.p, nullptr, (uint8_t *)ctx->io_b.p, n,
-                             stats, s, true);
-    if (rc != RT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(occluded, ctx->io_b.p, (size_t)n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return RT_OK;
+    return host_stream_trace(sc, nullptr, rays, nullptr, occluded, n, stats);
 }
 
 // ------------------------------------------------------------------------

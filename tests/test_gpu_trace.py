@@ -144,3 +144,53 @@ def test_golden_trace_fixture(rt, ctx):
     for k in COUNTERS:
         assert so[k] == want[k], k
     Sg.close()
+
+
+def test_host_entry_points_work_in_chunks(O, rt, ctx, scenes):
+    """rt_intersect_stream / rt_occluded_stream upload, trace and unpack their rays in chunks of 2^20:
+    a call of several chunks (the last one partial) gives what the device entry points give on the same
+    rays, rays are changed in their far distance only, and the counters are the sum over the chunks."""
+    import torch
+    sc = scenes.load("test-mesh", n_tris=20000, seed=3)
+    Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+    n = (1 << 21) + 12345
+    base = O.generate_primary(sc.camera, 640, 360, 10)[:n]
+    assert base.shape[0] == n
+    lib, C = rt._lib, rt.C
+
+    r = np.ascontiguousarray(base.copy())
+    hits = np.full(n, 123, dtype=np.uint32)
+    st = rt.TraceStats()
+    assert lib.rt_intersect_stream(Sg.h, rt._p(r), rt._p(hits), n, C.byref(st)) == 0
+    d_rays = torch.from_numpy(base.view(np.float32).reshape(n, 12).copy()).cuda()
+    d_hits = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st_dev = Sg.intersect_stream_device(d_rays.data_ptr(), d_hits.data_ptr(), n, stats=True)
+    torch.cuda.synchronize()
+    want_rays = d_rays.cpu().numpy().view(rt.RAY_DTYPE).reshape(n)
+    assert np.array_equal(hits, d_hits.cpu().numpy().view(np.uint32))
+    assert r.tobytes() == want_rays.tobytes()
+    changed = r["origin_far"][:, 3] != base["origin_far"][:, 3]
+    assert np.array_equal(changed, hits != rt.NO_HIT)
+    got = st.as_dict()
+    for k in COUNTERS:
+        assert got[k] == st_dev[k], k
+    # a slice against the oracle
+    So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+    io, to, _ = So.intersect_stream(base[-50000:])
+    assert assert_hits_match(io, to, hits[-50000:], r["origin_far"][-50000:, 3], "last chunk") == 0
+
+    occ = np.full(n, 7, dtype=np.uint8)
+    st2 = rt.TraceStats()
+    sh = np.ascontiguousarray(base.copy())
+    sh["origin_far"][:, 3] = 2.5
+    assert lib.rt_occluded_stream(Sg.h, rt._p(sh), rt._p(occ), n, C.byref(st2)) == 0
+    assert ctx.last_stats_split()[1]["total_rays"] == n          # summed over the chunks
+    d_sh = torch.from_numpy(sh.view(np.float32).reshape(n, 12).copy()).cuda()
+    d_occ = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    st2_dev = Sg.occluded_stream_device(d_sh.data_ptr(), d_occ.data_ptr(), n, stats=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(occ, d_occ.cpu().numpy())
+    assert set(np.unique(occ)) <= {0, 1}
+    for k in COUNTERS:
+        assert st2.as_dict()[k] == st2_dev[k], k
+    Sg.close()
