@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <thread>
+#include <vector>
 
 namespace rtc {
 
@@ -102,6 +104,21 @@ uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, 
 }
 
 namespace {
+
+unsigned worker_threads()
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::min(16u, std::max(1u, hw));
+}
+
+template <class F>
+void run_parallel(unsigned n, F fn)
+{
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n; t++) pool.emplace_back([&fn, t] { fn(t); });
+    fn(0);
+    for (auto &th : pool) th.join();
+}
 
 struct Box3 {
     float lo[3], hi[3];
@@ -237,17 +254,66 @@ uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const 
     xorder = order;
     xroot = root_ref;
     if (max_tris < 1 || max_tris >= 8) return 0;
-    Refiner rf{positions, indices, max_tris, &xn, &xorder};
     const size_t n = bn.size();
-    xn.reserve(n + n / 2 + 8);
-    for (size_t i = 0; i < n; i++) {
-        const uint32_t l = rf.refine_ref(bn[i].left);
-        const uint32_t r = rf.refine_ref(bn[i].right);
-        xn[i].left = l;
-        xn[i].right = r;
+    // Leaves are independent (each reorders only its own slots of xorder).  Every thread takes a
+    // contiguous range of the original nodes and collects the nodes it creates in a vector of its
+    // own, numbered from 0; joining the vectors in range order gives the numbering a single
+    // sequential pass would give.
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(worker_threads(), n / 4096 + 1));
+    std::vector<std::vector<DevNode>> made(T);
+    std::vector<uint32_t> deepest(T, 0);
+    const uint32_t kLocal = 0x40000000u; // marks a reference to a thread-local new node (inner refs stay below)
+    run_parallel(T, [&](unsigned t) {
+        Refiner rf{positions, indices, max_tris, &made[t], &xorder};
+        const size_t lo = n * t / T, hi = n * (t + 1) / T;
+        for (size_t i = lo; i < hi; i++) {
+            uint32_t l = rf.refine_ref(bn[i].left);
+            uint32_t r = rf.refine_ref(bn[i].right);
+            if (l != bn[i].left && !(l & kLeafBit)) l |= kLocal;
+            if (r != bn[i].right && !(r & kLeafBit)) r |= kLocal;
+            xn[i].left = l;
+            xn[i].right = r;
+        }
+        deepest[t] = rf.deepest;
+    });
+    std::vector<size_t> base(T + 1, n);
+    for (unsigned t = 0; t < T; t++) base[t + 1] = base[t] + made[t].size();
+    xn.resize(base[T]);
+    run_parallel(T, [&](unsigned t) {
+        const uint32_t b = (uint32_t)base[t];
+        for (size_t j = 0; j < made[t].size(); j++) { // references between new nodes are local indices
+            DevNode d = made[t][j];
+            if (!(d.left & kLeafBit)) d.left += b;
+            if (!(d.right & kLeafBit)) d.right += b;
+            xn[b + j] = d;
+        }
+        const size_t lo = n * t / T, hi = n * (t + 1) / T;
+        for (size_t i = lo; i < hi; i++) {
+            if (!(xn[i].left & kLeafBit) && (xn[i].left & kLocal)) xn[i].left = (xn[i].left & ~kLocal) + b;
+            if (!(xn[i].right & kLeafBit) && (xn[i].right & kLocal)) xn[i].right = (xn[i].right & ~kLocal) + b;
+        }
+    });
+    uint32_t deep = 0;
+    for (uint32_t d : deepest) deep = std::max(deep, d);
+    // the root is a leaf only in a tree without inner nodes
+    {
+        std::vector<DevNode> extra;
+        Refiner rf{positions, indices, max_tris, &extra, &xorder};
+        const uint32_t r = rf.refine_ref(root_ref);
+        if (r != root_ref && !(r & kLeafBit)) {
+            const uint32_t b = (uint32_t)xn.size();
+            for (DevNode d : extra) {
+                if (!(d.left & kLeafBit)) d.left += b;
+                if (!(d.right & kLeafBit)) d.right += b;
+                xn.push_back(d);
+            }
+            xroot = r + b;
+        } else {
+            xroot = r;
+        }
+        deep = std::max(deep, rf.deepest);
     }
-    xroot = rf.refine_ref(root_ref);
-    return rf.deepest;
+    return deep;
 }
 
 void quantize_wide4(const std::vector<DevWideNode> &wide, std::vector<DevQWideNode> &out,
@@ -255,7 +321,10 @@ void quantize_wide4(const std::vector<DevWideNode> &wide, std::vector<DevQWideNo
 {
     out.resize(wide.size());
     bin.resize(wide.size());
-    for (size_t w = 0; w < wide.size(); w++) {
+    const size_t total = wide.size();
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(worker_threads(), total / 4096 + 1));
+    run_parallel(T, [&](unsigned t) {
+    for (size_t w = total * t / T; w < total * (t + 1) / T; w++) {
         const DevWideNode &src = wide[w];
         DevQWideNode &q = out[w];
         bin[w] = src.bin;
@@ -301,6 +370,7 @@ void quantize_wide4(const std::vector<DevWideNode> &wide, std::vector<DevQWideNo
         }
         for (int i = 0; i < 4; i++) q.child[i] = src.child[i];
     }
+    });
 }
 
 } // namespace rtc
