@@ -184,6 +184,19 @@ extern "C" {
         info: *mut rt_scene_info,
         stats: *mut rt_bvh_stats,
     ) -> c_int;
+    pub fn rt_bvh_build_search_host(
+        positions: *const f32,
+        num_vertices: u32,
+        indices: *const u32,
+        num_triangles: u32,
+        threads: u32,
+        buckets: u32,
+        max_leaf: u32,
+        nodes: *mut rt_flat_node,
+        order: *mut u32,
+        info: *mut rt_scene_info,
+        stats: *mut rt_bvh_stats,
+    ) -> c_int;
     pub fn rt_bvh_wide_host(
         nodes: *const rt_flat_node,
         num_nodes: u32,

@@ -169,6 +169,11 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *   "fuse_primary"      0/1 (default 1): depth 0 of rt_render without ray and PathInfo queues;
  *                       the extend launch makes the camera rays itself.  Same image bit for
  *                       bit; not used by calls that ask for visit counters.
+ *   "fast_tree_buckets" 0 or 2..64 (default 32), read by rt_scene_create: the quantized 4-wide
+ *                       tree of forms 2 and 3 is collapsed from a tree of its own, built like the
+ *                       reference's (binned SAH) but with that many buckets, every axis tried and
+ *                       leaves of at most 3 triangles; 0 collapses it from the reference's tree.
+ *                       Forms 0 and 1 always walk the reference's tree.
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
  *   "sort_bits"         3..30 key bits that take part in the order
  *   "timing"            0/1 per-launch HIP events */
@@ -201,6 +206,17 @@ int rt_scene_get_flat(const rt_scene *scene, rt_flat_node *nodes, rt_flat_tri *t
 int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
                       uint32_t num_triangles, uint32_t threads, rt_flat_node *nodes, uint32_t *order,
                       rt_scene_info *info, rt_bvh_stats *stats);
+
+/* The builder of the tree the fast traversal forms walk (no counterpart in the
+ * reference): binned SAH like src/bvh/build.rs:45-207, but with `buckets`
+ * buckets (2..64), every axis that has a centroid extent tried instead of the
+ * largest one only, candidates with an empty side skipped, and leaves of at
+ * most max_leaf triangles (1..8; more only where all centroids coincide).
+ * Same output conventions as rt_bvh_build_host.  rt_scene_create runs it with
+ * (fast_tree_buckets, 3) unless that option is 0. */
+int rt_bvh_build_search_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                             uint32_t num_triangles, uint32_t threads, uint32_t buckets, uint32_t max_leaf,
+                             rt_flat_node *nodes, uint32_t *order, rt_scene_info *info, rt_bvh_stats *stats);
 
 /* 4-wide traversal form of the tree (no counterpart in the reference, whose tree
  * is binary, src/bvh.rs:19-34).
@@ -256,7 +272,9 @@ int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t roo
  * original nodes keep their indices, new nodes are appended; xorder is a
  * permutation of order that only moves triangles inside their reference leaf.
  * xnodes must hold num_nodes + num_triangles entries, xorder num_triangles.
- * rt_scene_create builds the wide tree over exactly this (max_tris = 3). */
+ * rt_scene_create builds the wide tree over exactly this (max_tris = 3) when
+ * the option "fast_tree_buckets" is 0, and over rt_bvh_build_search_host's
+ * tree otherwise. */
 int rt_bvh_refine_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
                        uint32_t num_triangles, const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref,
                        uint32_t root_count, const uint32_t *order, uint32_t max_tris, rt_flat_node *xnodes,

@@ -115,6 +115,8 @@ EXPORTS = {
     "rt_ctx_last_stats_split": (C.c_int, [_vp, C.POINTER(TraceStats * 2)]),
     "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
+    "rt_bvh_build_search_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp,
+                                           C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
     "rt_bvh_build_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
                                     C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
     "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32),
@@ -195,6 +197,20 @@ def build_bvh_host(positions, indices, threads=0):
     info, st = SceneInfo(), BvhStats()
     _check(_lib.rt_bvh_build_host(_p(pos), pos.shape[0], _p(idx), nt, int(threads), _p(nodes), _p(order),
                                   C.byref(info), C.byref(st)))
+    inf = {n: int(getattr(info, n)) for n, _ in SceneInfo._fields_}
+    return nodes[:inf["num_inner_nodes"]].copy(), order, inf, st.as_dict()
+
+
+def build_bvh_search_host(positions, indices, buckets=32, max_leaf=3, threads=0):
+    """rt_bvh_build_search_host: the builder of the fast forms' tree; same returns as build_bvh_host."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    nt = idx.shape[0]
+    nodes = np.zeros(nt, dtype=NODE_DTYPE)
+    order = np.zeros(nt, dtype=np.uint32)
+    info, st = SceneInfo(), BvhStats()
+    _check(_lib.rt_bvh_build_search_host(_p(pos), pos.shape[0], _p(idx), nt, int(threads), int(buckets), int(max_leaf),
+                                         _p(nodes), _p(order), C.byref(info), C.byref(st)))
     inf = {n: int(getattr(info, n)) for n, _ in SceneInfo._fields_}
     return nodes[:inf["num_inner_nodes"]].copy(), order, inf, st.as_dict()
 

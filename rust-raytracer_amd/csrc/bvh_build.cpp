@@ -23,7 +23,8 @@
 namespace rtc {
 namespace {
 
-constexpr int kBuckets = 8;
+constexpr int kBuckets = 8;     // the reference's builder
+constexpr int kMaxBuckets = 64; // the search builder
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kTaskTag = 0x40000000u; // placeholder ref: deferred subtree (top phase only)
 
@@ -107,9 +108,12 @@ inline void set_child(Emit &e, const Work &w, uint32_t ref, uint32_t count)
 // Builds the subtree over order[begin,end).  With `defer` non-null, ranges of
 // at most `grain` triangles (but more than a leaf) are not expanded; they are
 // recorded as tasks.
+template <bool SEARCH>
 void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t end, uint32_t depth,
-                 Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events)
+                 Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events, BuildTuning tune)
 {
+    const uint32_t max_leaf = SEARCH ? tune.max_leaf : 8u;
+    const int nb = SEARCH ? (int)tune.buckets : kBuckets;
     std::vector<Work> stack;
     stack.push_back({begin, end, depth, ~0u, 0});
     while (!stack.empty()) {
@@ -117,7 +121,7 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
         stack.pop_back();
         uint32_t n = w.end - w.begin;
 
-        bool leaf = (n >= 1 && n <= 8);
+        bool leaf = (n >= 1 && n <= max_leaf);
         Box bounds, cb;
         float size[3] = {0, 0, 0};
         if (!leaf) {
@@ -150,54 +154,65 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
 
         int axis = (size[0] > size[1] && size[0] > size[2]) ? 0 : (size[1] > size[2] ? 1 : 2);
         float k0 = cb.lo[axis];
-        float k1 = (float)kBuckets * (1.f - 0.01f) / (cb.hi[axis] - cb.lo[axis]);
-
-        Box bbox[kBuckets];
-        uint32_t bcnt[kBuckets];
-        for (int b = 0; b < kBuckets; b++) {
-            bbox[b].clear();
-            bcnt[b] = 0;
-        }
-        for (uint32_t i = w.begin; i < w.end; i++) {
-            const Prim &p = prims[order[i]];
-            uint32_t b = bucket_of(k0, k1, p.c[axis]);
-            bbox[b].add_box(p.box);
-            bcnt[b] += 1;
-        }
-
-        // prefix / suffix unions (min/max are exact, so the fold order of the
-        // reference's per-candidate folds does not matter)
-        Box pre[kBuckets], suf[kBuckets];
-        uint32_t pcnt[kBuckets], scnt[kBuckets];
-        pre[0] = bbox[0];
-        pcnt[0] = bcnt[0];
-        for (int b = 1; b < kBuckets; b++) {
-            pre[b] = pre[b - 1];
-            pre[b].add_box(bbox[b]);
-            pcnt[b] = pcnt[b - 1] + bcnt[b];
-        }
-        suf[kBuckets - 1] = bbox[kBuckets - 1];
-        scnt[kBuckets - 1] = bcnt[kBuckets - 1];
-        for (int b = kBuckets - 2; b >= 0; b--) {
-            suf[b] = suf[b + 1];
-            suf[b].add_box(bbox[b]);
-            scnt[b] = scnt[b + 1] + bcnt[b];
-        }
-
+        float k1 = (float)nb * (1.f - 0.01f) / (cb.hi[axis] - cb.lo[axis]);
         uint32_t min_bucket = 0;
-        float min_cost = std::numeric_limits<float>::infinity();
         Box bl, br;
         bl.clear();
         br.clear();
-        float parent_area = bounds.area();
-        for (int i = 0; i < kBuckets - 1; i++) {
-            float cost =
-                (pre[i].area() * (float)pcnt[i] + suf[i + 1].area() * (float)scnt[i + 1]) / parent_area;
-            if (cost < min_cost) {
-                min_bucket = (uint32_t)i;
-                min_cost = cost;
-                bl = pre[i];
-                br = suf[i + 1];
+        {
+            float min_cost = std::numeric_limits<float>::infinity();
+            const float parent_area = bounds.area();
+            // the reference looks along the axis of largest centroid extent only; the search
+            // builder tries every axis that has one
+            for (int ax = 0; ax < 3; ax++) {
+                if (SEARCH ? !(size[ax] > 0.f) : ax != axis) continue;
+                const float a0 = cb.lo[ax];
+                const float a1 = (float)nb * (1.f - 0.01f) / (cb.hi[ax] - cb.lo[ax]);
+                Box bbox[kMaxBuckets];
+                uint32_t bcnt[kMaxBuckets];
+                for (int b = 0; b < nb; b++) {
+                    bbox[b].clear();
+                    bcnt[b] = 0;
+                }
+                for (uint32_t i = w.begin; i < w.end; i++) {
+                    const Prim &p = prims[order[i]];
+                    uint32_t b = bucket_of(a0, a1, p.c[ax]);
+                    if (SEARCH && b >= (uint32_t)nb) b = (uint32_t)nb - 1u;
+                    bbox[b].add_box(p.box);
+                    bcnt[b] += 1;
+                }
+                // prefix / suffix unions (min/max are exact, so the fold order of the
+                // reference's per-candidate folds does not matter)
+                Box pre[kMaxBuckets], suf[kMaxBuckets];
+                uint32_t pcnt[kMaxBuckets], scnt[kMaxBuckets];
+                pre[0] = bbox[0];
+                pcnt[0] = bcnt[0];
+                for (int b = 1; b < nb; b++) {
+                    pre[b] = pre[b - 1];
+                    pre[b].add_box(bbox[b]);
+                    pcnt[b] = pcnt[b - 1] + bcnt[b];
+                }
+                suf[nb - 1] = bbox[nb - 1];
+                scnt[nb - 1] = bcnt[nb - 1];
+                for (int b = nb - 2; b >= 0; b--) {
+                    suf[b] = suf[b + 1];
+                    suf[b].add_box(bbox[b]);
+                    scnt[b] = scnt[b + 1] + bcnt[b];
+                }
+                for (int i = 0; i < nb - 1; i++) {
+                    if (SEARCH && (pcnt[i] == 0 || scnt[i + 1] == 0)) continue;
+                    float cost =
+                        (pre[i].area() * (float)pcnt[i] + suf[i + 1].area() * (float)scnt[i + 1]) / parent_area;
+                    if (cost < min_cost) {
+                        min_bucket = (uint32_t)i;
+                        min_cost = cost;
+                        bl = pre[i];
+                        br = suf[i + 1];
+                        axis = ax;
+                        k0 = a0;
+                        k1 = a1;
+                    }
+                }
             }
         }
 
@@ -229,6 +244,15 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
     }
 }
 
+void run_range(bool search, const Prim *prims, uint32_t *order, uint32_t begin, uint32_t end, uint32_t depth,
+               Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events, BuildTuning tune)
+{
+    if (search)
+        build_range<true>(prims, order, begin, end, depth, e, defer, grain, track_events, tune);
+    else
+        build_range<false>(prims, order, begin, end, depth, e, defer, grain, track_events, tune);
+}
+
 void merge_stats(rt_bvh_stats &a, const rt_bvh_stats &b) // src/bvh/build.rs:35-42
 {
     a.num_leaves += b.num_leaves;
@@ -240,9 +264,13 @@ void merge_stats(rt_bvh_stats &a, const rt_bvh_stats &b) // src/bvh/build.rs:35-
 } // namespace
 
 void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uint32_t nt,
-               unsigned threads, HostBvh &out)
+               unsigned threads, HostBvh &out, const BuildTuning *tuning)
 {
     (void)nv;
+    const bool search = tuning != nullptr;
+    BuildTuning tune = search ? *tuning : BuildTuning{8, 8};
+    tune.buckets = std::min<uint32_t>(std::max<uint32_t>(tune.buckets, 2), kMaxBuckets);
+    tune.max_leaf = std::min<uint32_t>(std::max<uint32_t>(tune.max_leaf, 1), 8);
     std::vector<Prim> prims(nt);
     out.order.resize(nt);
     auto fill = [&](uint32_t t0, uint32_t t1) {
@@ -263,7 +291,7 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
     if (threads == 1 || nt < 200000) {
         fill(0, nt);
         Emit e;
-        build_range(prims.data(), out.order.data(), 0, nt, 0, e, nullptr, 0, false);
+        run_range(search, prims.data(), out.order.data(), 0, nt, 0, e, nullptr, 0, false, tune);
         out.nodes.swap(e.nodes);
         out.root_ref = e.root_ref;
         out.root_count = e.root_count;
@@ -285,7 +313,7 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
     Emit top;
     std::vector<Deferred> tasks;
     uint32_t grain = std::max<uint32_t>(4096, nt / (threads * 16));
-    build_range(prims.data(), out.order.data(), 0, nt, 0, top, &tasks, grain, true);
+    run_range(search, prims.data(), out.order.data(), 0, nt, 0, top, &tasks, grain, true, tune);
 
     // parallel phase: every task builds its subtree with local node indices
     std::vector<Emit> sub(tasks.size());
@@ -294,8 +322,8 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
         for (;;) {
             size_t i = next.fetch_add(1);
             if (i >= tasks.size()) break;
-            build_range(prims.data(), out.order.data(), tasks[i].begin, tasks[i].end, tasks[i].depth,
-                        sub[i], nullptr, 0, false);
+            run_range(search, prims.data(), out.order.data(), tasks[i].begin, tasks[i].end, tasks[i].depth,
+                      sub[i], nullptr, 0, false, tune);
         }
     };
     {

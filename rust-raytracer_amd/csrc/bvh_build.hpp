@@ -21,9 +21,19 @@ struct HostBvh {
     rt_bvh_stats stats{};
 };
 
+// The search builder (no counterpart in the reference): the same binned SAH
+// with more buckets, every axis with a centroid extent tried, and smaller
+// leaves.  Used for the tree the fast traversal forms walk; the reference's
+// tree stays what the exact forms walk.
+struct BuildTuning {
+    uint32_t buckets;  // 2..64
+    uint32_t max_leaf; // 1..8 triangles
+};
+
 // positions: 3*nv floats; indices: 3*nt.  `threads` > 1 builds disjoint
-// subtrees concurrently (the result does not depend on it).
+// subtrees concurrently (the result does not depend on it).  tuning == nullptr:
+// the reference's builder.
 void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uint32_t nt,
-               unsigned threads, HostBvh &out);
+               unsigned threads, HostBvh &out, const BuildTuning *tuning = nullptr);
 
 } // namespace rtc

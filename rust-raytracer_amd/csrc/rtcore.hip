@@ -110,6 +110,7 @@ struct rt_ctx {
     unsigned min_active[2] = {40, 40}; // [0] closest-hit, [1] any-hit launches
     // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
     // while-while form wins), [1] for deeper launches and the stream entry points
+    unsigned fast_tree_buckets = 32; // >= 2: the fast forms get a tree from the search builder with that many buckets; 0: the reference's tree
     unsigned trav_mode[2] = {3, 2};
     // the stream entry points are the reference's Bvh::intersect_stream / occluded_stream
     // boundary and walk the reference's binary tree unless told otherwise
@@ -353,6 +354,8 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->min_active[0] = ctx->min_active[1] = (unsigned)value;
     } else if (n == "fuse_primary" && in(0, 1)) {
         ctx->fuse_primary = (unsigned)value;
+    } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
+        ctx->fast_tree_buckets = (unsigned)value;
     } else if (n == "traversal_stream" && in(0, 3)) {
         ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
@@ -563,7 +566,24 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     std::vector<DevNode> xdn;
     std::vector<uint32_t> xorder;
     uint32_t xroot = root;
-    const uint32_t extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, xdn, xroot, xorder);
+    uint32_t extra_depth = 0, fast_depth = hb.stats.max_depth;
+    unsigned search_buckets = ctx->fast_tree_buckets;
+    if (const char *env = getenv("RTCORE_FAST_TREE_BUCKETS")) {
+        const int v = atoi(env);
+        if (v == 0 || (v >= 2 && v <= 64)) search_buckets = (unsigned)v;
+    }
+    if (search_buckets >= 2) {
+        // the fast forms walk a tree of their own: same builder family, wider search (bvh_build.hpp)
+        HostBvh hs;
+        const BuildTuning tune{search_buckets, leaf_tris};
+        build_bvh(positions, num_vertices, indices, num_triangles, threads, hs, &tune);
+        std::vector<DevNode> sdn;
+        const uint32_t sroot = make_dev_nodes(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, sdn, big);
+        extra_depth = refine_leaves(sdn, sroot, positions, indices, hs.order, leaf_tris, xdn, xroot, xorder);
+        fast_depth = hs.stats.max_depth;
+    } else {
+        extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, xdn, xroot, xorder);
+    }
     std::vector<DevTri> xdt;
     make_tris(xorder, xdt);
     xdt.resize(xdt.size() + 1, DevTri{}); // the scalar path reads a triangle as 64 bytes
@@ -599,7 +619,7 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
     // Deepest traversal stack of a lane.  Binary walk: one deferred sibling per level.
     // Wide walk: up to three deferred children per wide level.
-    sc->stack_bound = std::max(hb.stats.max_depth + extra_depth, 3u * wide_depth) + 1u;
+    sc->stack_bound = std::max(std::max(hb.stats.max_depth, fast_depth + extra_depth), 3u * wide_depth) + 1u;
     if (rc == RT_OK) rc = ensure_overflow(ctx, sc->stack_bound);
     if (rc != RT_OK) {
         rt_scene_destroy(sc);
@@ -628,32 +648,32 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     sc->dev.wbin = (const uint32_t *)sc->wbin.p;
     sc->dev.xnodes = (const DevNode *)sc->xnodes.p;
     sc->dev.xtris = (const DevTri *)sc->xtris.p;
-    sc->dev.xmax_depth = hb.stats.max_depth + extra_depth;
+    sc->dev.xmax_depth = fast_depth + extra_depth;
     sc->dev.wroot_ref = wroot;
     sc->dev.max_depth = hb.stats.max_depth;
     *out = sc;
     return RT_OK;
 }
 
-extern "C" int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
-                                 uint32_t num_triangles, uint32_t threads, rt_flat_node *nodes, uint32_t *order,
-                                 rt_scene_info *info, rt_bvh_stats *stats)
+static int bvh_build_host_impl(const char *who, const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                               uint32_t num_triangles, uint32_t threads, const BuildTuning *tuning, rt_flat_node *nodes,
+                               uint32_t *order, rt_scene_info *info, rt_bvh_stats *stats)
 {
     if (!positions || !indices || !nodes || !order)
-        return fail(RT_ERR_INVALID, "rt_bvh_build_host: NULL argument");
-    if (num_triangles == 0 || num_vertices == 0) return fail(RT_ERR_INVALID, "rt_bvh_build_host: empty mesh");
+        return fail(RT_ERR_INVALID, "%s: NULL argument", who);
+    if (num_triangles == 0 || num_vertices == 0) return fail(RT_ERR_INVALID, "%s: empty mesh", who);
     for (size_t i = 0; i < (size_t)num_triangles * 3; i++)
         if (indices[i] >= num_vertices)
-            return fail(RT_ERR_INVALID, "rt_bvh_build_host: index %u at %zu out of range", indices[i], i);
+            return fail(RT_ERR_INVALID, "%s: index %u at %zu out of range", who, indices[i], i);
     if (threads == 0) {
         unsigned hw = std::thread::hardware_concurrency();
         threads = hw ? std::min(hw, 16u) : 4u;
     }
     HostBvh hb;
     try {
-        build_bvh(positions, num_vertices, indices, num_triangles, threads, hb);
+        build_bvh(positions, num_vertices, indices, num_triangles, threads, hb, tuning);
     } catch (const std::exception &ex) {
-        return fail(RT_ERR_NOMEM, "rt_bvh_build_host: %s", ex.what());
+        return fail(RT_ERR_NOMEM, "%s: %s", who, ex.what());
     }
     if (!hb.nodes.empty()) memcpy(nodes, hb.nodes.data(), hb.nodes.size() * sizeof(rt_flat_node));
     memcpy(order, hb.order.data(), hb.order.size() * sizeof(uint32_t));
@@ -666,6 +686,25 @@ extern "C" int rt_bvh_build_host(const float *positions, uint32_t num_vertices, 
     }
     if (stats) *stats = hb.stats;
     return RT_OK;
+}
+
+extern "C" int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                                 uint32_t num_triangles, uint32_t threads, rt_flat_node *nodes, uint32_t *order,
+                                 rt_scene_info *info, rt_bvh_stats *stats)
+{
+    return bvh_build_host_impl("rt_bvh_build_host", positions, num_vertices, indices, num_triangles, threads, nullptr,
+                               nodes, order, info, stats);
+}
+
+extern "C" int rt_bvh_build_search_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                                        uint32_t num_triangles, uint32_t threads, uint32_t buckets, uint32_t max_leaf,
+                                        rt_flat_node *nodes, uint32_t *order, rt_scene_info *info, rt_bvh_stats *stats)
+{
+    if (buckets < 2 || buckets > 64 || max_leaf < 1 || max_leaf > 8)
+        return fail(RT_ERR_INVALID, "rt_bvh_build_search_host: buckets 2..64, max_leaf 1..8");
+    const BuildTuning tune{buckets, max_leaf};
+    return bvh_build_host_impl("rt_bvh_build_search_host", positions, num_vertices, indices, num_triangles, threads,
+                               &tune, nodes, order, info, stats);
 }
 
 extern "C" int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref,

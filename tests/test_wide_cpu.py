@@ -172,3 +172,99 @@ def test_refined_leaves(rt, scenes, name, kw, max_tris):
             first, count, _, _ = subtree(xref, xcnt)
             assert first == (ref & 0x7FFFFFFF) and count == cnt
             assert sorted(xorder[first:first + count].tolist()) == sorted(order[first:first + count].tolist())
+
+
+def subtree_bounds(nodes, order, tri_lo, tri_hi, ref, cnt, seen, leaf_sizes):
+    """Exact bounds of the triangles under `ref`, checking on the way that every inner node's two child
+    boxes contain their subtrees (iterative post-order)."""
+    result = {}
+    stack = [(ref, cnt, False)]
+    while stack:
+        r, c, done = stack.pop()
+        if r & LEAF:
+            first = r & 0x7FFFFFFF
+            ids = order[first:first + c]
+            seen[ids] += 1
+            leaf_sizes.append(c)
+            result[(r, c)] = (tri_lo[ids].min(axis=0), tri_hi[ids].max(axis=0))
+            continue
+        n = nodes[r]
+        kids = [(int(n["left"]), int(n["left_count"])), (int(n["right"]), int(n["right_count"]))]
+        if not done:
+            stack.append((r, c, True))
+            stack.extend((k[0], k[1], False) for k in kids)
+            continue
+        boxes = []
+        for side, k in enumerate(kids):
+            lo, hi = result.pop((k[0], k[1]))
+            blo = np.array([n["bx"][side], n["by"][side], n["bz"][side]])
+            bhi = np.array([n["bx"][2 + side], n["by"][2 + side], n["bz"][2 + side]])
+            assert (blo <= lo).all() and (bhi >= hi).all(), "child box does not contain its triangles"
+            boxes.append((lo, hi))
+        result[(r, c)] = (np.minimum(boxes[0][0], boxes[1][0]), np.maximum(boxes[0][1], boxes[1][1]))
+    return result[(ref, cnt)]
+
+
+def sah_cost(nodes, root):
+    """Sum over inner nodes of the two child areas (times 1) -- the quantity binned SAH minimises
+    greedily, relative comparisons only."""
+    def area(lo, hi):
+        d = np.maximum(hi - lo, 0)
+        return 2 * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2])
+    total = 0.0
+    for n in nodes:
+        for side in range(2):
+            lo = np.array([n["bx"][side], n["by"][side], n["bz"][side]], dtype=np.float64)
+            hi = np.array([n["bx"][2 + side], n["by"][2 + side], n["bz"][2 + side]], dtype=np.float64)
+            cnt = int(n["left_count" if side == 0 else "right_count"])
+            total += area(lo, hi) * max(cnt, 1)
+    return total
+
+
+@pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 3000, "seed": 4}),
+                                     ("test-mesh", {"n_tris": 20000, "seed": 3})])
+@pytest.mark.parametrize("buckets,max_leaf", [(32, 3), (8, 8), (2, 1)])
+def test_search_builder_invariants(rt, scenes, name, kw, buckets, max_leaf):
+    """The builder of the fast forms' tree: every triangle in exactly one leaf, leaves within the size
+    limit (unless all centroids of a leaf coincide), child boxes contain their triangles, the result
+    does not depend on the thread count, and the tree is valid input for the 4-wide collapse."""
+    sc = scenes.load(name, **kw)
+    nodes, order, info, st = rt.build_bvh_search_host(sc.positions, sc.indices, buckets, max_leaf, threads=1)
+    nodes4, order4, info4, st4 = rt.build_bvh_search_host(sc.positions, sc.indices, buckets, max_leaf, threads=4)
+    assert nodes.tobytes() == nodes4.tobytes() and np.array_equal(order, order4) and info == info4 and st == st4
+    nt = len(sc.indices)
+    assert sorted(order.tolist()) == list(range(nt))
+    tri = sc.positions[sc.indices]                       # [nt, 3, 3]
+    tri_lo, tri_hi = tri.min(axis=1), tri.max(axis=1)
+    seen = np.zeros(nt, dtype=np.int64)
+    sizes = []
+    subtree_bounds(nodes, order, tri_lo, tri_hi, info["root_ref"], info["root_count"], seen, sizes)
+    assert (seen == 1).all()
+    assert st["num_objs"] == nt and st["num_leaves"] == len(sizes) and st["max_objs"] == max(sizes)
+    cent = (tri[:, 0] + tri[:, 1] + tri[:, 2]) / np.float32(3)
+    if max(sizes) > max_leaf:                            # only leaves whose centroids all coincide may be larger
+        stack = [(info["root_ref"], info["root_count"])]
+        while stack:
+            r, c = stack.pop()
+            if r & LEAF:
+                if c > max_leaf:
+                    ids = order[(r & 0x7FFFFFFF):(r & 0x7FFFFFFF) + c]
+                    assert (cent[ids] == cent[ids][0]).all()
+                continue
+            n = nodes[r]
+            stack.append((int(n["left"]), int(n["left_count"])))
+            stack.append((int(n["right"]), int(n["right_count"])))
+    if max(sizes) <= 8:
+        wide, qwide, wroot, depth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
+        assert len(wide) >= 1 or nt <= 8
+
+
+def test_search_builder_is_not_worse_than_the_reference_builder(rt, scenes):
+    """Same leaf limit, same bucket count: trying every axis can only lower the greedy cost at each
+    split; over a whole tree the summed child areas should not grow."""
+    sc = scenes.load("test-mesh", n_tris=20000, seed=3)
+    ref_nodes, _, _, _ = rt.build_bvh_host(sc.positions, sc.indices)
+    s_nodes, _, _, _ = rt.build_bvh_search_host(sc.positions, sc.indices, 8, 8)
+    s32_nodes, _, _, _ = rt.build_bvh_search_host(sc.positions, sc.indices, 32, 8)
+    c_ref, c8, c32 = sah_cost(ref_nodes, 0), sah_cost(s_nodes, 0), sah_cost(s32_nodes, 0)
+    assert c8 <= c_ref * 1.02 and c32 <= c_ref * 1.02, (c_ref, c8, c32)
