@@ -254,7 +254,8 @@ typedef struct rt_qwide_node {
 
 /* Derives the 4-wide forms from a canonical flat tree on the host: children of
  * inner children are pulled up, largest surface area first, until a node has
- * four.  out and qout may be NULL and otherwise hold num_nodes entries each
+ * four; the children of a wide node are then ordered largest box first (the
+ * order in which the any-hit walk visits hit children).  out and qout may be NULL and otherwise hold num_nodes entries each
  * (the wide tree never has more nodes than the binary one); nodes are written
  * in depth-first pre-order.  wide_root_ref is 0, or the leaf reference when the
  * root is a leaf.  rt_scene_create runs the same code. */

@@ -77,13 +77,18 @@ uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, 
                 }
             }
             if (pick < 0) break;
-            // the two children take the place of the opened child, keeping the left-to-right order
+            // the two children take the place of the opened child
             for (int i = n - 1; i > pick; i--) c[i + 1] = c[i];
             const uint32_t opened = c[pick].ref;
             children_of(bn[opened], c[pick], c[pick + 1]);
             n++;
         }
 
+        // Slot order is the order the any-hit walk visits hit children in.  Left to right (the
+        // binary tree's order, which follows the split axis whatever the ray's direction) measured
+        // 3-20 % slower there than any order by box size; largest first is the one kept.  The
+        // closest-hit walk orders by entry distance and only falls back to slots on ties.
+        std::stable_sort(c, c + n, [](const Slot &a, const Slot &b) { return a.area() > b.area(); });
         DevWideNode &w = out[self];
         for (int i = 0; i < 4; i++) {
             const bool used = i < n;
