@@ -155,3 +155,47 @@ def test_full_size_fast_mode_against_exact_mode(rt, ctx, ctx_default, scenes, na
     assert differs.mean() < 5e-3, differs.mean()
     rmse = float(np.sqrt(np.mean((af[..., :3] / spp - ae[..., :3] / spp) ** 2)))
     assert rmse < 2e-3, rmse
+
+
+@pytest.mark.parametrize("form", [2, 3])
+def test_fast_forms_on_degenerate_leaves(O, rt, ctx_default, scenes, form):
+    """A mesh whose tree has a root leaf, and one with clusters of 20 coincident triangles inside a
+    larger mesh (leaves beyond 8 triangles in both builders): the fast forms still find the oracle's hits."""
+    ctx = ctx_default
+    ctx.set_option("traversal_stream", form)
+    try:
+        pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+        Sg = rt.Scene(ctx, pos, np.array([[0, 1, 2]], np.uint32), np.array([[0, 0, 1]], np.float32))
+        rays = rt.make_rays([[0.25, 0.25, 1.0], [2.0, 2.0, 1.0]], [[0, 0, -1.0], [0, 0, -1.0]])
+        ids, t, _ = Sg.intersect_stream(rays, stats=False)
+        assert ids.tolist() == [0, rt.NO_HIT] and t[0] == 1.0
+        Sg.close()
+
+        sc = scenes.load("test-mesh", n_tris=3000, seed=4)
+        base = len(sc.positions)
+        extra_pos = np.array([[0.1, 0.1, 5.0], [0.4, 0.1, 5.0], [0.1, 0.4, 5.0],
+                              [-0.5, -0.5, -5.0], [-0.2, -0.5, -5.0], [-0.5, -0.2, -5.0]], np.float32)
+        positions = np.vstack([sc.positions, extra_pos]).astype(np.float32)
+        dup = np.vstack([np.tile(np.array([[base, base + 1, base + 2]], np.uint32), (20, 1)),
+                         np.tile(np.array([[base + 3, base + 4, base + 5]], np.uint32), (20, 1))])
+        indices = np.vstack([sc.indices, dup]).astype(np.uint32)
+        normals = np.vstack([sc.geom_normals, np.tile(np.array([[0, 0, 1]], np.float32), (40, 1))]).astype(np.float32)
+        So = O.Scene(positions, indices, normals)
+        Sg = rt.Scene(ctx, positions, indices, normals)
+        lo, hi = positions.min(), positions.max()
+        rnd = random_rays(O.make_rays, 20000, 5, lo=lo, hi=hi)
+        aimed = rt.make_rays([[0.2, 0.2, 9.0], [-0.4, -0.4, -9.0], [0.2, 0.2, 9.0]],
+                             [[0, 0, -1.0], [0, 0, 1.0], [0, 0, 1.0]])
+        for rays, what in ((rnd, "random"), (aimed, "aimed at the clusters")):
+            io, to, _ = So.intersect_stream(rays)
+            ig, tg, _ = Sg.intersect_stream(rays, stats=False)
+            same = (tg == to) | (np.isinf(tg) & np.isinf(to))
+            assert same.mean() > 1 - 5e-4, what
+            og, _ = Sg.occluded_stream(rays, stats=False)
+            assert (og.astype(bool) == (io != rt.NO_HIT)).mean() > 1 - 5e-4, what
+        ig, tg, _ = Sg.intersect_stream(aimed, stats=False)
+        assert tg[0] == 4.0 and tg[1] == 4.0 and ig[2] == rt.NO_HIT
+        assert len(sc.indices) <= ig[0] < len(sc.indices) + 20 and len(sc.indices) + 20 <= ig[1]
+        Sg.close()
+    finally:
+        ctx.set_option("traversal_stream", 1)
