@@ -392,6 +392,7 @@ int main(int argc, char **argv)
         rt_ctx_set_option(ctx, "traversal_depth0", 0);
         rt_ctx_set_option(ctx, "traversal_deep", 1);
         rt_ctx_set_option(ctx, "coop_steps", 0);
+        rt_ctx_set_option(ctx, "fast_tree_buckets", 0); // no second tree: nothing walks it
     }
     auto t_bvh = std::chrono::steady_clock::now();
     rt_scene *scene = nullptr;
