@@ -175,6 +175,7 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       leaves of at most 3 triangles; 0 collapses it from the reference's tree.
  *                       Forms 0 and 1 always walk the reference's tree.
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
+ *                       (defaults: never = 0xFFFFFFFF for the bounce rays, 1 for the shadow rays)
  *   "sort_bits"         3..30 key bits that take part in the order
  *   "timing"            0/1 per-launch HIP events */
 int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value);

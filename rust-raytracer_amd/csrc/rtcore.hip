@@ -120,7 +120,7 @@ struct rt_ctx {
     unsigned fuse_primary = 1;
     // queues are reordered by the Morton code of the ray origin from these depths
     // on (depth of the launch that consumes the queue); 0xFFFFFFFF = never
-    unsigned sort_from_depth[2] = {2, 1}; // [0] extend, [1] connect
+    unsigned sort_from_depth[2] = {0xFFFFFFFFu, 1}; // [0] extend (never), [1] connect
     unsigned sort_bits = 21;              // high bits of the 30-bit key that are sorted
     Workspace ws;
     // Queue lengths of the last finished render pass, read back asynchronously: the next pass

@@ -140,3 +140,25 @@ def test_fused_primary_is_bit_identical(rt, ctx, scenes):
     finally:
         ctx.set_option("fuse_primary", 1)
     Sg.close()
+
+
+def test_queue_order_does_not_change_the_image(rt, ctx, scenes):
+    """Morton-ordered or not, shadow and bounce queues give the same accumulator bit for bit (radiance
+    is kept per path slot and summed in a fixed order) and the same ray counts."""
+    sc = scenes.load("test-mesh", n_tris=4000, seed=9)
+    Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+    never = 0xFFFFFFFF
+    out = {}
+    try:
+        for name, (ext, con) in {"none": (never, never), "default": (never, 1), "both": (1, 0), "late": (2, 2)}.items():
+            ctx.set_option("sort_extend_from", ext)
+            ctx.set_option("sort_connect_from", con)
+            out[name] = Sg.render(sc.camera, sc.light, 160, 90, 4, max_bounces=3)
+    finally:
+        ctx.set_option("sort_extend_from", never)
+        ctx.set_option("sort_connect_from", 1)
+    a0, s0 = out["none"]
+    for name, (a, s) in out.items():
+        assert np.array_equal(a, a0), name
+        assert s["total_rays"] == s0["total_rays"], name
+    Sg.close()
