@@ -19,6 +19,10 @@
 #ifndef RTC_ANYHIT_SORTED
 #define RTC_ANYHIT_SORTED 0
 #endif
+// 1: the coherent depth-0 kernels are built for more resident waves than the others (TraceTune)
+#ifndef RTC_TRACE_TUNED
+#define RTC_TRACE_TUNED 1
+#endif
 #ifndef RTC_TRACE_WAVES_PER_SIMD
 #define RTC_TRACE_WAVES_PER_SIMD 5
 #endif

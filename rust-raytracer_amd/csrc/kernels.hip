@@ -1094,14 +1094,38 @@ struct QueueIO { // render pipeline queues
 
 struct PrimaryIO; // depth-0 closest-hit launches that make their own camera rays (defined below the camera code)
 
+// Resident waves per SIMD the compiler allocates registers for, and LDS stack entries per lane, by
+// kernel.  The coherent launches gain from more waves (measured on the Sponza-class frame: depth-0
+// extend +3.5 % at 6 waves, depth-0 connect +5 % at 8 waves with 16 LDS entries, a few registers
+// spilled in both); the stepwise forms for incoherent rays lose far more to the tighter register
+// budget than they gain (San-Miguel-class extend -19 % at 6).
 template <bool ANYHIT, bool STATS, int MODE, class IO>
-__global__ __launch_bounds__(kBlock, RTC_TRACE_WAVES_PER_SIMD) void trace_kernel(SceneDev sc, IO io, const unsigned *n_ptr, unsigned n_val,
+struct TraceTune {
+    static constexpr int waves = RTC_TRACE_WAVES_PER_SIMD;
+    static constexpr int lds_depth = kLdsDepth;
+};
+#if RTC_TRACE_TUNED
+template <>
+struct TraceTune<false, false, 3, PrimaryIO> {
+    static constexpr int waves = 6;
+    static constexpr int lds_depth = kLdsDepth;
+};
+template <>
+struct TraceTune<true, false, 3, QueueIO> {
+    static constexpr int waves = 8;
+    static constexpr int lds_depth = 16;
+};
+#endif
+
+template <bool ANYHIT, bool STATS, int MODE, class IO>
+__global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)) void trace_kernel(SceneDev sc, IO io, const unsigned *n_ptr, unsigned n_val,
                                                       TraceLaunch tl)
 {
-    __shared__ unsigned lds_stack[kLdsDepth * kBlock];
+    constexpr int kDepth = TraceTune<ANYHIT, STATS, MODE, IO>::lds_depth;
+    __shared__ unsigned lds_stack[kDepth * kBlock];
     const unsigned n = n_ptr ? *n_ptr : n_val;
     const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
-    Stack<kBlock, kLdsDepth> st;
+    Stack<kBlock, kDepth> st;
     st.lds = lds_stack + threadIdx.x;
     st.ovf = tl.ovf + gtid;
     st.ovf_stride = gridDim.x * kBlock;
@@ -1677,24 +1701,30 @@ static unsigned trace_grid(unsigned n, unsigned max_blocks)
     return need < max_blocks ? need : max_blocks;
 }
 
+template <bool ANYHIT, bool STATS, int MODE, class IO>
+static void launch_one(const SceneDev &sc, const IO &io, const unsigned *n_ptr, unsigned n_val, unsigned grid,
+                       const TraceLaunch &tl, hipStream_t stream)
+{
+    // The grid is the same for every trace kernel (the most blocks any of them can keep resident);
+    // blocks of a kernel with a lower occupancy start when the first ones end and find the queue empty.
+    hipLaunchKernelGGL((trace_kernel<ANYHIT, STATS, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io, n_ptr,
+                       n_val, tl);
+}
+
 template <int MODE, class IO>
 static void launch_trace_mode(bool anyhit, bool stats, const SceneDev &sc, const IO &io, const unsigned *n_ptr,
                               unsigned n_val, unsigned grid, const TraceLaunch &tl, hipStream_t stream)
 {
     if (anyhit) {
         if (stats)
-            hipLaunchKernelGGL((trace_kernel<true, true, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                               n_ptr, n_val, tl);
+            launch_one<true, true, MODE, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
         else
-            hipLaunchKernelGGL((trace_kernel<true, false, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                               n_ptr, n_val, tl);
+            launch_one<true, false, MODE, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
     } else {
         if (stats)
-            hipLaunchKernelGGL((trace_kernel<false, true, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                               n_ptr, n_val, tl);
+            launch_one<false, true, MODE, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
         else
-            hipLaunchKernelGGL((trace_kernel<false, false, MODE, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                               n_ptr, n_val, tl);
+            launch_one<false, false, MODE, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
     }
 }
 
@@ -1708,18 +1738,14 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
         // 4-wide tree, no visit counters in these forms
         if (tl.mode == 2) {
             if (anyhit)
-                hipLaunchKernelGGL((trace_kernel<true, false, 2, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                                   n_ptr, n_val, tl);
+                launch_one<true, false, 2, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
             else
-                hipLaunchKernelGGL((trace_kernel<false, false, 2, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                                   n_ptr, n_val, tl);
+                launch_one<false, false, 2, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
         } else {
             if (anyhit)
-                hipLaunchKernelGGL((trace_kernel<true, false, 3, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                                   n_ptr, n_val, tl);
+                launch_one<true, false, 3, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
             else
-                hipLaunchKernelGGL((trace_kernel<false, false, 3, IO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                                   n_ptr, n_val, tl);
+                launch_one<false, false, 3, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
         }
     }
     else if (tl.mode == 0)
@@ -1761,20 +1787,16 @@ void launch_extend_primary(const SceneDev &sc, const CameraDev &cam, const PassD
     const unsigned mode = (tl.mode >= 2 && !sc.wnodes) ? 1u : tl.mode;
     switch (mode) {
     case 0:
-        hipLaunchKernelGGL((trace_kernel<false, false, 0, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                           nullptr, n, tl);
+        launch_one<false, false, 0, PrimaryIO>(sc, io, nullptr, n, grid, tl, stream);
         break;
     case 1:
-        hipLaunchKernelGGL((trace_kernel<false, false, 1, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                           nullptr, n, tl);
+        launch_one<false, false, 1, PrimaryIO>(sc, io, nullptr, n, grid, tl, stream);
         break;
     case 2:
-        hipLaunchKernelGGL((trace_kernel<false, false, 2, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                           nullptr, n, tl);
+        launch_one<false, false, 2, PrimaryIO>(sc, io, nullptr, n, grid, tl, stream);
         break;
     default:
-        hipLaunchKernelGGL((trace_kernel<false, false, 3, PrimaryIO>), dim3(grid), dim3(kBlock), 0, stream, sc, io,
-                           nullptr, n, tl);
+        launch_one<false, false, 3, PrimaryIO>(sc, io, nullptr, n, grid, tl, stream);
         break;
     }
 }
@@ -1853,6 +1875,8 @@ int trace_blocks_per_cu()
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<false, false, 1, QueueIO>, kBlock, 0) == hipSuccess && v > best) best = v;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<true, false, 0, QueueIO>, kBlock, 0) == hipSuccess && v > best) best = v;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<false, true, 1, StreamIO>, kBlock, 0) == hipSuccess && v > best) best = v;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<true, false, 3, QueueIO>, kBlock, 0) == hipSuccess && v > best) best = v;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, trace_kernel<false, false, 3, PrimaryIO>, kBlock, 0) == hipSuccess && v > best) best = v;
     if (best > 8) best = 8;
     return best;
 }
