@@ -23,6 +23,24 @@
 #ifndef RTC_TRACE_TUNED
 #define RTC_TRACE_TUNED 1
 #endif
+#ifndef RTC_TUNE_PRIMARY_WAVES
+#define RTC_TUNE_PRIMARY_WAVES 6
+#endif
+#ifndef RTC_TUNE_PRIMARY_LDS
+#define RTC_TUNE_PRIMARY_LDS RTC_LDS_STACK_DEPTH
+#endif
+#ifndef RTC_TUNE_ANY3_WAVES
+#define RTC_TUNE_ANY3_WAVES 8
+#endif
+#ifndef RTC_TUNE_ANY3_LDS
+#define RTC_TUNE_ANY3_LDS 16
+#endif
+#ifndef RTC_TUNE_ANY2_WAVES
+#define RTC_TUNE_ANY2_WAVES 5
+#endif
+#ifndef RTC_TUNE_ANY2_LDS
+#define RTC_TUNE_ANY2_LDS RTC_LDS_STACK_DEPTH
+#endif
 #ifndef RTC_TRACE_WAVES_PER_SIMD
 #define RTC_TRACE_WAVES_PER_SIMD 5
 #endif

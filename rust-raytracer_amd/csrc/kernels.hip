@@ -1107,13 +1107,18 @@ struct TraceTune {
 #if RTC_TRACE_TUNED
 template <>
 struct TraceTune<false, false, 3, PrimaryIO> {
-    static constexpr int waves = 6;
-    static constexpr int lds_depth = kLdsDepth;
+    static constexpr int waves = RTC_TUNE_PRIMARY_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_PRIMARY_LDS;
 };
 template <>
 struct TraceTune<true, false, 3, QueueIO> {
-    static constexpr int waves = 8;
-    static constexpr int lds_depth = 16;
+    static constexpr int waves = RTC_TUNE_ANY3_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_ANY3_LDS;
+};
+template <>
+struct TraceTune<true, false, 2, QueueIO> {
+    static constexpr int waves = RTC_TUNE_ANY2_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_ANY2_LDS;
 };
 #endif
 
