@@ -106,14 +106,24 @@ __device__ __forceinline__ void block_reserve(const bool (&pred)[NQ][ITEMS], uns
             const unsigned up = (unsigned)__shfl_up((int)incl, off);
             if ((lane % (ITEMS * NW)) >= (unsigned)off) incl += up;
         }
-        // last entry of each queue holds that queue's total
-        unsigned base = 0;
+        // last entry of each queue holds that queue's total; lane q reserves for queue q, so the
+        // atomics of all queues are in flight together (one round trip, not NQ)
+        unsigned my_total = 0;
+        unsigned *my_counter = counters[0];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const unsigned total = (unsigned)__shfl((int)incl, (q + 1) * ITEMS * NW - 1);
-            unsigned b = 0;
-            if (lane == 0 && total != 0) b = atomicAdd(counters[q], total);
-            b = (unsigned)__shfl((int)b, 0);
+            if (lane == (unsigned)q) {
+                my_total = total;
+                my_counter = counters[q];
+            }
+        }
+        unsigned reserved = 0;
+        if (lane < (unsigned)NQ && my_total != 0) reserved = atomicAdd(my_counter, my_total);
+        unsigned base = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const unsigned b = (unsigned)__shfl((int)reserved, q);
             if (q_of == (unsigned)q) base = b;
         }
         if (lane < E) lds[lane] = base + incl - mine;
