@@ -194,3 +194,18 @@ def test_host_entry_points_work_in_chunks(O, rt, ctx, scenes):
     for k in COUNTERS:
         assert st2.as_dict()[k] == st2_dev[k], k
     Sg.close()
+
+
+def test_size_limits_are_errors(rt, ctx):
+    """Sizes beyond what the packed leaf references hold are refused with RT_ERR_LIMIT before any
+    buffer is read (the reference panics on its own limits: src/bvh/intersect_stream.rs:16)."""
+    C, lib = rt.C, rt._lib
+    pos = np.zeros((3, 3), np.float32)
+    idx = np.zeros((1, 3), np.uint32)
+    nrm = np.zeros((1, 3), np.float32)
+    out = C.c_void_p()
+    rc = lib.rt_scene_create(ctx.h, rt._p(pos), 3, rt._p(idx), 1 << 27, rt._p(nrm), C.byref(out))
+    assert rc == 4 and b"limit" in lib.rt_last_error()
+    assert not out.value
+    rc = lib.rt_scene_create(ctx.h, rt._p(pos), 3, rt._p(idx), 0, rt._p(nrm), C.byref(out))
+    assert rc == 1
