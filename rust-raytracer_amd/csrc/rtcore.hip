@@ -93,7 +93,9 @@ struct Workspace {
 
 } // namespace
 
-constexpr uint32_t kMaxQueueCounters = 1024; // queue-length words of one pass kept for the next pass's sort sizes
+constexpr uint32_t kCounterStride = 32;      // queue-length words sit in 128-byte lines of their own (the blocks of a
+                                             // shade launch add to two of them at once)
+constexpr uint32_t kMaxQueueCounters = 2048; // words (stride included) of one pass kept for the next pass's sort sizes
 
 struct rt_ctx {
     int device = 0;
@@ -1215,7 +1217,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
     const uint32_t nb = params->max_bounces + 1; // extend launches per pass
     // per pass: ray count per depth (nb+1), shadow count per depth (nb), then the
     // ray-fetch counters of the 2*nb trace launches; zeroed by one memset
-    const uint32_t nqueue = (2 * nb + 2 + 31u) & ~31u;
+    const uint32_t nqueue = (2 * nb + 2) * kCounterStride;
     const uint32_t ncounters = nqueue + 2 * nb * kFetchUints;
     // a queue consumed at depth d is sorted when d >= sort_from_depth
     const bool sort_any = (nb > ctx->sort_from_depth[0]) || (nb > ctx->sort_from_depth[1]);
@@ -1255,7 +1257,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
 
             // queue lengths of the previous pass, if its read-back has landed (never waited for)
             if (ctx->counts_pending && hipEventQuery(ctx->counts_ready) == hipSuccess) {
-                ctx->est_counts.assign(ctx->h_counts, ctx->h_counts + 2 * (size_t)ctx->pending_key[2] + 1);
+                const size_t words = 2 * (size_t)ctx->pending_key[2] + 1;
+                ctx->est_counts.resize(words);
+                for (size_t i = 0; i < words; i++) ctx->est_counts[i] = ctx->h_counts[i * kCounterStride];
                 memcpy(ctx->est_key, ctx->pending_key, sizeof ctx->est_key);
                 ctx->counts_pending = false;
             }
@@ -1268,8 +1272,8 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 return (uint32_t)std::min<uint64_t>(e, ps.num_slots);
             };
             HIP_TRY(hipMemsetAsync(counters, 0, (size_t)ncounters * sizeof(uint32_t), s));
-            uint32_t *n_ray = counters;          // [0..nb]
-            uint32_t *n_sh = counters + nb + 1;  // [0..nb-1]
+            auto n_ray = [&](uint32_t i) { return counters + (size_t)i * kCounterStride; };            // [0..nb]
+            auto n_sh = [&](uint32_t i) { return counters + (size_t)(nb + 1 + i) * kCounterStride; }; // [0..nb-1]
             uint32_t *fetch = counters + nqueue; // [2*nb][kFetchUints]
             int cur = 0;
             size_t slot;
@@ -1288,9 +1292,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                     const uint32_t tx = (uint32_t)(tile % tiles_x), ty = (uint32_t)(tile / tiles_x);
                     valid_px += (uint64_t)std::min(ts, params->width - tx * ts) * std::min(ts, params->height - ty * ts);
                 }
-                launch_set_count(&n_ray[0], (unsigned)(valid_px * ps.samples_this_pass), s);
+                launch_set_count(n_ray(0), (unsigned)(valid_px * ps.samples_this_pass), s);
             } else {
-                launch_generate(cam, ps, (QRay *)w.rays[cur].p, (PathInfo *)w.infos[cur].p, &n_ray[0], rad_r, rad_g,
+                launch_generate(cam, ps, (QRay *)w.rays[cur].p, (PathInfo *)w.infos[cur].p, n_ray(0), rad_r, rad_g,
                                 rad_b, s);
             }
             rc = timed_end(ctx, slot, s);
@@ -1305,17 +1309,17 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                     launch_extend_primary(sc->dev, cam, ps, (uint32_t *)w.hit_ids.p, (float *)w.hit_t.p, tle,
                                           ctx->max_blocks, s);
                 else
-                    launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, &n_ray[b],
+                    launch_extend(visit, sc->dev, (QRay *)w.rays[cur].p, (uint32_t *)w.hit_ids.p, n_ray(b),
                                   ps.num_slots, tle, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
-                if (want && !visit) launch_count_rays(&n_ray[b], dstats, s);
+                if (want && !visit) launch_count_rays(n_ray(b), dstats, s);
 
                 ShadeArgs a{};
                 a.rays_in = (const QRay *)w.rays[cur].p;
                 a.infos_in = (const PathInfo *)w.infos[cur].p;
                 a.hit_ids = (const uint32_t *)w.hit_ids.p;
-                a.n_in = &n_ray[b];
+                a.n_in = n_ray(b);
                 if (fused && b == 0) {
                     a.primary = 1;
                     a.n_in = nullptr;
@@ -1327,10 +1331,10 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 a.normals = sc->dev.normals;
                 a.rays_out = (QRay *)w.rays[cur ^ 1].p;
                 a.infos_out = (PathInfo *)w.infos[cur ^ 1].p;
-                a.n_out = &n_ray[b + 1];
+                a.n_out = n_ray(b + 1);
                 a.shadow_rays = (QRay *)w.shadow_rays.p;
                 a.shadow_infos = (ShadowInfo *)w.shadow_infos.p;
-                a.n_shadow = &n_sh[b];
+                a.n_shadow = n_sh(b);
                 memcpy(a.light_pos, light->pos, sizeof a.light_pos);
                 memcpy(a.light_intensity, light->intensity, sizeof a.light_intensity);
                 a.max_bounces = params->max_bounces;
@@ -1389,10 +1393,10 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                                 ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, perm_connect_n, nullptr, 0, 0};
                 fill_coop(ctx, sc, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
-                               &n_sh[b], ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
+                               n_sh(b), ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
-                if (want && !visit) launch_count_rays(&n_sh[b], dstats + 1, s);
+                if (want && !visit) launch_count_rays(n_sh(b), dstats + 1, s);
                 cur ^= 1;
             }
             rc = timed_begin(ctx, 2, s, &slot);
@@ -1400,8 +1404,8 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             launch_accumulate(ps, rad_r, rad_g, rad_b, d_accum, s);
             rc = timed_end(ctx, slot, s);
             if (rc != RT_OK) return rc;
-            if (sort_any && !ctx->counts_pending && 2 * nb + 1 <= kMaxQueueCounters) {
-                HIP_TRY(hipMemcpyAsync(ctx->h_counts, counters, (size_t)(2 * nb + 1) * sizeof(uint32_t),
+            if (sort_any && !ctx->counts_pending && (2 * nb + 1) * kCounterStride <= kMaxQueueCounters) {
+                HIP_TRY(hipMemcpyAsync(ctx->h_counts, counters, (size_t)(2 * nb + 1) * kCounterStride * sizeof(uint32_t),
                                        hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipEventRecord(ctx->counts_ready, s));
                 ctx->counts_pending = true;
