@@ -166,7 +166,9 @@ static int ctx_set_device(rt_ctx *ctx) { HIP_TRY(hipSetDevice(ctx->device)); ret
 
 static int ensure_overflow(rt_ctx *ctx, unsigned max_depth)
 {
-    unsigned need = max_depth + 1 > (unsigned)RTC_LDS_STACK_DEPTH ? max_depth + 1 - RTC_LDS_STACK_DEPTH : 1;
+    // entries a lane can need beyond the LDS part of its stack, for the kernel with the smallest LDS part
+    constexpr unsigned in_lds = (unsigned)(RTC_MIN_LDS_STACK_DEPTH);
+    unsigned need = max_depth + 1 > in_lds ? max_depth + 1 - in_lds : 1;
     if (need <= ctx->ovf_depth) return RT_OK;
     size_t threads = (size_t)ctx->max_blocks * RTC_TRACE_BLOCK;
     int rc = ctx->ovf.ensure(threads * need * sizeof(unsigned));
