@@ -23,6 +23,9 @@
 #ifndef RTC_TRACE_TUNED
 #define RTC_TRACE_TUNED 1
 #endif
+#ifndef RTC_TUNE_EXACT_WAVES
+#define RTC_TUNE_EXACT_WAVES RTC_TRACE_WAVES_PER_SIMD
+#endif
 #ifndef RTC_TUNE_PRIMARY_WAVES
 #define RTC_TUNE_PRIMARY_WAVES 6
 #endif

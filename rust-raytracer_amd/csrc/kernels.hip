@@ -1115,6 +1115,16 @@ struct TraceTune {
     static constexpr int lds_depth = kLdsDepth;
 };
 #if RTC_TRACE_TUNED
+template <bool ANYHIT, class IO> // exact forms without visit counters
+struct TraceTune<ANYHIT, false, 0, IO> {
+    static constexpr int waves = RTC_TUNE_EXACT_WAVES;
+    static constexpr int lds_depth = kLdsDepth;
+};
+template <bool ANYHIT, class IO>
+struct TraceTune<ANYHIT, false, 1, IO> {
+    static constexpr int waves = RTC_TUNE_EXACT_WAVES;
+    static constexpr int lds_depth = kLdsDepth;
+};
 template <>
 struct TraceTune<false, false, 3, PrimaryIO> {
     static constexpr int waves = RTC_TUNE_PRIMARY_WAVES;
