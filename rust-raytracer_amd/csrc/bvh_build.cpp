@@ -71,6 +71,22 @@ inline uint32_t bucket_of(float k0, float k1, float c)
     return (uint32_t)f;
 }
 
+// Runs fn(t, lo, hi) on `threads` threads over [begin, end) cut into equal slices.
+template <class F>
+void parallel_slices(unsigned threads, uint32_t begin, uint32_t end, F fn)
+{
+    const uint32_t n = end - begin;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++)
+        pool.emplace_back([=, &fn] { fn(t, begin + (uint32_t)((uint64_t)n * t / threads), begin + (uint32_t)((uint64_t)n * (t + 1) / threads)); });
+    fn(0u, begin, begin + (uint32_t)((uint64_t)n / threads));
+    for (auto &th : pool) th.join();
+}
+
+// ranges of at least this many triangles are scanned by all threads of the top phase (the unions and
+// counts are exact whatever the order, so the tree does not depend on it)
+constexpr uint32_t kParallelScan = 1u << 17;
+
 struct Work {
     uint32_t begin, end; // range in the order array
     uint32_t depth;
@@ -110,7 +126,8 @@ inline void set_child(Emit &e, const Work &w, uint32_t ref, uint32_t count)
 // recorded as tasks.
 template <bool SEARCH>
 void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t end, uint32_t depth,
-                 Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events, BuildTuning tune)
+                 Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events, BuildTuning tune,
+                 unsigned scan_threads)
 {
     const uint32_t max_leaf = SEARCH ? tune.max_leaf : 8u;
     const int nb = SEARCH ? (int)tune.buckets : kBuckets;
@@ -134,10 +151,30 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
             }
             bounds.clear();
             cb.clear();
-            for (uint32_t i = w.begin; i < w.end; i++) {
-                const Prim &p = prims[order[i]];
-                bounds.add_box(p.box);
-                cb.add_point(p.c);
+            if (scan_threads > 1 && n >= kParallelScan) {
+                std::vector<Box> part(2 * (size_t)scan_threads);
+                parallel_slices(scan_threads, w.begin, w.end, [&](unsigned t, uint32_t lo, uint32_t hi) {
+                    Box b, c;
+                    b.clear();
+                    c.clear();
+                    for (uint32_t i = lo; i < hi; i++) {
+                        const Prim &p = prims[order[i]];
+                        b.add_box(p.box);
+                        c.add_point(p.c);
+                    }
+                    part[2 * t] = b;
+                    part[2 * t + 1] = c;
+                });
+                for (unsigned t = 0; t < scan_threads; t++) {
+                    bounds.add_box(part[2 * t]);
+                    cb.add_box(part[2 * t + 1]);
+                }
+            } else {
+                for (uint32_t i = w.begin; i < w.end; i++) {
+                    const Prim &p = prims[order[i]];
+                    bounds.add_box(p.box);
+                    cb.add_point(p.c);
+                }
             }
             for (int a = 0; a < 3; a++) size[a] = cb.hi[a] - cb.lo[a];
             float nsq = (size[0] * size[0] + size[1] * size[1]) + size[2] * size[2];
@@ -174,12 +211,39 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
                     bbox[b].clear();
                     bcnt[b] = 0;
                 }
-                for (uint32_t i = w.begin; i < w.end; i++) {
-                    const Prim &p = prims[order[i]];
-                    uint32_t b = bucket_of(a0, a1, p.c[ax]);
-                    if (SEARCH && b >= (uint32_t)nb) b = (uint32_t)nb - 1u;
-                    bbox[b].add_box(p.box);
-                    bcnt[b] += 1;
+                if (scan_threads > 1 && n >= kParallelScan) {
+                    struct Bins {
+                        Box box[kMaxBuckets];
+                        uint32_t cnt[kMaxBuckets];
+                    };
+                    std::vector<Bins> part(scan_threads);
+                    parallel_slices(scan_threads, w.begin, w.end, [&](unsigned t, uint32_t lo, uint32_t hi) {
+                        Bins &m = part[t];
+                        for (int b = 0; b < nb; b++) {
+                            m.box[b].clear();
+                            m.cnt[b] = 0;
+                        }
+                        for (uint32_t i = lo; i < hi; i++) {
+                            const Prim &p = prims[order[i]];
+                            uint32_t b = bucket_of(a0, a1, p.c[ax]);
+                            if (SEARCH && b >= (uint32_t)nb) b = (uint32_t)nb - 1u;
+                            m.box[b].add_box(p.box);
+                            m.cnt[b] += 1;
+                        }
+                    });
+                    for (unsigned t = 0; t < scan_threads; t++)
+                        for (int b = 0; b < nb; b++) {
+                            bbox[b].add_box(part[t].box[b]);
+                            bcnt[b] += part[t].cnt[b];
+                        }
+                } else {
+                    for (uint32_t i = w.begin; i < w.end; i++) {
+                        const Prim &p = prims[order[i]];
+                        uint32_t b = bucket_of(a0, a1, p.c[ax]);
+                        if (SEARCH && b >= (uint32_t)nb) b = (uint32_t)nb - 1u;
+                        bbox[b].add_box(p.box);
+                        bcnt[b] += 1;
+                    }
                 }
                 // prefix / suffix unions (min/max are exact, so the fold order of the
                 // reference's per-candidate folds does not matter)
@@ -245,12 +309,13 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
 }
 
 void run_range(bool search, const Prim *prims, uint32_t *order, uint32_t begin, uint32_t end, uint32_t depth,
-               Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events, BuildTuning tune)
+               Emit &e, std::vector<Deferred> *defer, uint32_t grain, bool track_events, BuildTuning tune,
+               unsigned scan_threads = 1)
 {
     if (search)
-        build_range<true>(prims, order, begin, end, depth, e, defer, grain, track_events, tune);
+        build_range<true>(prims, order, begin, end, depth, e, defer, grain, track_events, tune, scan_threads);
     else
-        build_range<false>(prims, order, begin, end, depth, e, defer, grain, track_events, tune);
+        build_range<false>(prims, order, begin, end, depth, e, defer, grain, track_events, tune, scan_threads);
 }
 
 void merge_stats(rt_bvh_stats &a, const rt_bvh_stats &b) // src/bvh/build.rs:35-42
@@ -312,8 +377,8 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
     // top phase: expand until ranges are small, remember the rest as tasks
     Emit top;
     std::vector<Deferred> tasks;
-    uint32_t grain = std::max<uint32_t>(4096, nt / (threads * 16));
-    run_range(search, prims.data(), out.order.data(), 0, nt, 0, top, &tasks, grain, true, tune);
+    uint32_t grain = std::max<uint32_t>(4096, nt / (threads * 8));
+    run_range(search, prims.data(), out.order.data(), 0, nt, 0, top, &tasks, grain, true, tune, threads);
 
     // parallel phase: every task builds its subtree with local node indices
     std::vector<Emit> sub(tasks.size());

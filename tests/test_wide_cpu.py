@@ -272,3 +272,17 @@ def test_search_builder_is_not_worse_than_the_reference_builder(rt, scenes):
     s32_nodes, _, _, _ = rt.build_bvh_search_host(sc.positions, sc.indices, 32, 8)
     c_ref, c8, c32 = sah_cost(ref_nodes, 0), sah_cost(s_nodes, 0), sah_cost(s32_nodes, 0)
     assert c8 <= c_ref * 1.02 and c32 <= c_ref * 1.02, (c_ref, c8, c32)
+
+
+def test_builders_do_not_depend_on_the_thread_count(rt, scenes):
+    """Above 200,000 triangles both builders run their top levels with all threads scanning large
+    ranges together and build the subtrees below as parallel tasks; unions and counts are exact, so
+    the tree is the one a single thread builds."""
+    sc = scenes.load("sponza-class")
+    assert len(sc.indices) > 200000
+    for build in (lambda th: rt.build_bvh_host(sc.positions, sc.indices, threads=th),
+                  lambda th: rt.build_bvh_search_host(sc.positions, sc.indices, 32, 3, threads=th)):
+        n1, o1, i1, s1 = build(1)
+        for th in (3, 8):
+            n, o, i, s = build(th)
+            assert n.tobytes() == n1.tobytes() and np.array_equal(o, o1) and i == i1 and s == s1
