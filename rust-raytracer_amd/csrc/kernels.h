@@ -61,7 +61,10 @@ namespace rtc {
 
 // Ray-fetch counters of one trace launch: kFetchRanges counters, each alone in
 // a 128-byte line.
-constexpr unsigned kFetchRanges = 32;
+#ifndef RTC_FETCH_RANGES
+#define RTC_FETCH_RANGES 32
+#endif
+constexpr unsigned kFetchRanges = RTC_FETCH_RANGES;
 constexpr unsigned kFetchStride = 32; // uints between counters
 constexpr unsigned kFetchUints = kFetchRanges * kFetchStride;
 
