@@ -115,7 +115,25 @@ struct PassDev {
     uint32_t sample_base;            // global index of sample 0 of this pass
     uint32_t num_slots;              // tile_count * tile_size^2 * samples_per_pass
     uint32_t seed_key;
+    // derived (fill_pass_shifts): log2 of samples_per_pass, tile_size and tile_size^2 where these
+    // are powers of two, else 0xFFFFFFFF; num_slots / samples_per_pass
+    uint32_t k_shift, ts_shift, ts2_shift, pixel_slots;
 };
+
+inline uint32_t pow2_shift(uint32_t v)
+{
+    if (v == 0 || (v & (v - 1u)) != 0) return 0xFFFFFFFFu;
+    uint32_t s = 0;
+    while ((1u << s) != v) s++;
+    return s;
+}
+inline void fill_pass_shifts(PassDev &ps)
+{
+    ps.k_shift = pow2_shift(ps.samples_per_pass);
+    ps.ts_shift = pow2_shift(ps.tile_size);
+    ps.ts2_shift = ps.ts_shift == 0xFFFFFFFFu ? 0xFFFFFFFFu : 2u * ps.ts_shift;
+    ps.pixel_slots = ps.samples_per_pass ? ps.num_slots / ps.samples_per_pass : 0u;
+}
 
 struct ShadeArgs {
     // depth 0 without queues (primary != 0): ray and PathInfo of entry i are rebuilt from pass slot

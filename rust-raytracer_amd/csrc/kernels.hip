@@ -1349,12 +1349,12 @@ __device__ __forceinline__ V3 rotate(Quat q, V3 x)
 // ------------------------------------------------------------------------
 // generate: camera rays (src/camera.rs:56-135, integrate_stream.rs:14-54)
 
-__device__ __forceinline__ V3 camera_pixel_ray(const CameraDev &cam, unsigned tile_size, unsigned x, unsigned y)
+// (rx, ry) is the top-left pixel of the tile that holds (x, y)
+__device__ __forceinline__ V3 camera_pixel_ray(const CameraDev &cam, unsigned rx, unsigned ry, unsigned x, unsigned y)
 {
     // region_top_left of the tile, then the row start, then x advanced by
     // repeated += (src/camera.rs:72-75, 98-113) so that rounding matches the
     // reference's per-tile walk.
-    const unsigned rx = x / tile_size * tile_size, ry = y / tile_size * tile_size;
     const V3 tl = v3(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
     const V3 sx = v3(cam.step_x[0], cam.step_x[1], cam.step_x[2]);
     const V3 sy = v3(cam.step_y[0], cam.step_y[1], cam.step_y[2]);
@@ -1381,21 +1381,42 @@ __device__ __forceinline__ V3 camera_sample(const CameraDev &cam, V3 pixel_ray, 
 constexpr int kGenItems = 8;
 constexpr int kGenBlock = 512;
 
+// Division by a pass constant: a shift when the constant is a power of two (tile size 16, tile area
+// 256 and the usual samples per pass are), the general division otherwise.  `shift` is 0xFFFFFFFF
+// when the divisor is not a power of two.
+__device__ __forceinline__ void divmod(unsigned n, unsigned d, unsigned shift, unsigned &q, unsigned &r)
+{
+    if (shift != 0xFFFFFFFFu) { // uniform over the launch
+        q = n >> shift;
+        r = n & (d - 1u);
+    } else {
+        q = n / d;
+        r = n - q * d;
+    }
+}
+
+// Pixel (x, y), the top-left pixel (rx, ry) of its tile, sample index s and pixel slot p of a pass slot.
+__device__ __forceinline__ bool slot_to_pixel(const PassDev &ps, unsigned slot, unsigned &x, unsigned &y,
+                                              unsigned &s, unsigned &rx, unsigned &ry, unsigned &p)
+{
+    if (slot >= ps.num_slots) return false;
+    unsigned pin, tl, px, py;
+    divmod(slot, ps.samples_per_pass, ps.k_shift, p, s);
+    divmod(p, ps.tile_size * ps.tile_size, ps.ts2_shift, tl, pin);
+    const unsigned tile = ps.shard_index + (ps.tile_begin + tl) * ps.shard_count;
+    const unsigned ty = tile / ps.tiles_x, tx = tile - ty * ps.tiles_x;
+    divmod(pin, ps.tile_size, ps.ts_shift, py, px);
+    rx = tx * ps.tile_size;
+    ry = ty * ps.tile_size;
+    x = rx + px;
+    y = ry + py;
+    return (x < ps.width) && (y < ps.height) && (s < ps.samples_this_pass);
+}
 __device__ __forceinline__ bool slot_to_pixel(const PassDev &ps, unsigned slot, unsigned &x, unsigned &y,
                                               unsigned &s)
 {
-    if (slot >= ps.num_slots) return false;
-    const unsigned k = ps.samples_per_pass;
-    const unsigned ts2 = ps.tile_size * ps.tile_size;
-    s = slot % k;
-    const unsigned p = slot / k;
-    const unsigned pin = p % ts2;
-    const unsigned tl = p / ts2;
-    const unsigned tile = ps.shard_index + (ps.tile_begin + tl) * ps.shard_count;
-    const unsigned tx = tile % ps.tiles_x, ty = tile / ps.tiles_x;
-    x = tx * ps.tile_size + pin % ps.tile_size;
-    y = ty * ps.tile_size + pin / ps.tile_size;
-    return (x < ps.width) && (y < ps.height) && (s < ps.samples_this_pass);
+    unsigned rx, ry, p;
+    return slot_to_pixel(ps, slot, x, y, s, rx, ry, p);
 }
 
 // Primary path of pass slot `slot`: the camera ray of generate_rays
@@ -1404,12 +1425,12 @@ __device__ __forceinline__ bool slot_to_pixel(const PassDev &ps, unsigned slot, 
 __device__ __forceinline__ bool primary_path(const CameraDev &cam, const PassDev &ps, unsigned slot, QRay &q,
                                              PathInfo &pi)
 {
-    unsigned x, y, sidx;
-    if (!slot_to_pixel(ps, slot, x, y, sidx)) return false;
+    unsigned x, y, sidx, rx, ry, p;
+    if (!slot_to_pixel(ps, slot, x, y, sidx, rx, ry, p)) return false;
     const unsigned pixel = y * ps.width + x;
     const unsigned gs = ps.sample_base + sidx;
     const unsigned key = rng_key(ps.seed_key, pixel, gs);
-    const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
+    const V3 pr = camera_pixel_ray(cam, rx, ry, x, y);
     const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
     q.o[0] = cam.eye[0];
     q.o[1] = cam.eye[1];
@@ -1421,7 +1442,7 @@ __device__ __forceinline__ bool primary_path(const CameraDev &cam, const PassDev
     q.far_t = __builtin_inff();
     pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
     // radiance index: sample-major over the pass's pixel slots (see accumulate_kernel)
-    pi.slot = sidx * (ps.num_slots / ps.samples_per_pass) + slot / ps.samples_per_pass;
+    pi.slot = sidx * ps.pixel_slots + p;
     pi.pixel = pixel;
     pi.sample = gs;
     pi.bounces = 0;
@@ -1472,7 +1493,7 @@ __global__ __launch_bounds__(256) void generate_stream_kernel(CameraDev cam, Pas
     const unsigned x = pixel % ps.width, y = pixel / ps.width;
     const unsigned gs = ps.sample_base + s;
     const unsigned key = rng_key(ps.seed_key, pixel, gs);
-    const V3 pr = camera_pixel_ray(cam, ps.tile_size, x, y);
+    const V3 pr = camera_pixel_ray(cam, x / ps.tile_size * ps.tile_size, y / ps.tile_size * ps.tile_size, x, y);
     const V3 d = camera_sample(cam, pr, rng_f32(key, 0u), rng_f32(key, 1u));
     rt_stream_ray_dev r;
     r.origin_far = make_float4(cam.eye[0], cam.eye[1], cam.eye[2], __builtin_inff());

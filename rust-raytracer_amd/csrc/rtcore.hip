@@ -1255,6 +1255,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             ps.samples_this_pass = std::min(k, params->samples - s0);
             ps.sample_base = params->sample_offset + s0;
             ps.num_slots = tcount * ts2 * k;
+            fill_pass_shifts(ps);
             ps.seed_key = seed_key;
 
             // queue lengths of the previous pass, if its read-back has landed (never waited for)
