@@ -18,6 +18,7 @@
 #include <atomic>
 #include <cmath>
 #include <limits>
+#include <stdexcept>
 #include <thread>
 
 namespace rtc {
@@ -105,6 +106,10 @@ struct Emit {
     // top phase only: pre-order sequence of events; value = node index, or
     // kTaskTag | task index.
     std::vector<uint32_t> events;
+    // Set where the reference would panic (a bucket index beyond its bucket array,
+    // src/bvh/build.rs:118-120) or a partition leaves one side empty.  The builder carries on
+    // with a clamped bucket or a leaf, so that worker threads never throw, and build_bvh reports it.
+    bool failed = false;
 };
 
 inline void set_child(Emit &e, const Work &w, uint32_t ref, uint32_t count)
@@ -215,6 +220,7 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
                     struct Bins {
                         Box box[kMaxBuckets];
                         uint32_t cnt[kMaxBuckets];
+                        bool failed = false;
                     };
                     std::vector<Bins> part(scan_threads);
                     parallel_slices(scan_threads, w.begin, w.end, [&](unsigned t, uint32_t lo, uint32_t hi) {
@@ -226,21 +232,29 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
                         for (uint32_t i = lo; i < hi; i++) {
                             const Prim &p = prims[order[i]];
                             uint32_t b = bucket_of(a0, a1, p.c[ax]);
-                            if (SEARCH && b >= (uint32_t)nb) b = (uint32_t)nb - 1u;
+                            if (b >= (uint32_t)nb) {
+                                b = (uint32_t)nb - 1u;
+                                if (!SEARCH) m.failed = true;
+                            }
                             m.box[b].add_box(p.box);
                             m.cnt[b] += 1;
                         }
                     });
-                    for (unsigned t = 0; t < scan_threads; t++)
+                    for (unsigned t = 0; t < scan_threads; t++) {
+                        if (part[t].failed) e.failed = true;
                         for (int b = 0; b < nb; b++) {
                             bbox[b].add_box(part[t].box[b]);
                             bcnt[b] += part[t].cnt[b];
                         }
+                    }
                 } else {
                     for (uint32_t i = w.begin; i < w.end; i++) {
                         const Prim &p = prims[order[i]];
                         uint32_t b = bucket_of(a0, a1, p.c[ax]);
-                        if (SEARCH && b >= (uint32_t)nb) b = (uint32_t)nb - 1u;
+                        if (b >= (uint32_t)nb) {
+                            b = (uint32_t)nb - 1u;
+                            if (!SEARCH) e.failed = true;
+                        }
                         bbox[b].add_box(p.box);
                         bcnt[b] += 1;
                     }
@@ -282,13 +296,25 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
 
         uint32_t *idx = order + w.begin;
         uint32_t left = 0, right = n - 1;
+        // The reference's loops (src/bvh/build.rs:152-168) stop on a checked index; here the bounds
+        // are explicit, and a partition with an empty side (impossible for finite centroids: the
+        // smallest one is in bucket 0, the largest in the last) ends the subtree with a leaf.
         for (;;) {
-            while (bucket_of(k0, k1, prims[idx[left]].c[axis]) <= min_bucket) left++;
-            while (bucket_of(k0, k1, prims[idx[right]].c[axis]) > min_bucket) right--;
+            while (left < n && bucket_of(k0, k1, prims[idx[left]].c[axis]) <= min_bucket) left++;
+            while (right > 0 && bucket_of(k0, k1, prims[idx[right]].c[axis]) > min_bucket) right--;
             if (left >= right) break;
             std::swap(idx[left], idx[right]);
         }
         uint32_t split = left;
+        if (split == 0 || split >= n) {
+            e.failed = true;
+            set_child(e, w, kLeaf | w.begin, n);
+            e.stats.num_leaves += 1;
+            e.stats.num_objs += n;
+            e.stats.max_depth = std::max(e.stats.max_depth, w.depth);
+            e.stats.max_objs = std::max(e.stats.max_objs, n);
+            continue;
+        }
 
         uint32_t me = (uint32_t)e.nodes.size();
         rt_flat_node nd{};
@@ -317,6 +343,9 @@ void run_range(bool search, const Prim *prims, uint32_t *order, uint32_t begin, 
     else
         build_range<false>(prims, order, begin, end, depth, e, defer, grain, track_events, tune, scan_threads);
 }
+
+const char *const kDegenerate =
+    "centroid range the binning cannot resolve (bucket index out of range; the reference panics here)";
 
 void merge_stats(rt_bvh_stats &a, const rt_bvh_stats &b) // src/bvh/build.rs:35-42
 {
@@ -357,6 +386,7 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
         fill(0, nt);
         Emit e;
         run_range(search, prims.data(), out.order.data(), 0, nt, 0, e, nullptr, 0, false, tune);
+        if (e.failed) throw std::invalid_argument(kDegenerate);
         out.nodes.swap(e.nodes);
         out.root_ref = e.root_ref;
         out.root_count = e.root_count;
@@ -396,6 +426,10 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
         for (unsigned i = 0; i < threads; i++) pool.emplace_back(worker);
         for (auto &t : pool) t.join();
     }
+
+    bool failed = top.failed;
+    for (const Emit &se : sub) failed = failed || se.failed;
+    if (failed) throw std::invalid_argument(kDegenerate);
 
     // splice in pre-order
     std::vector<uint32_t> top_final(top.nodes.size()), task_base(tasks.size());

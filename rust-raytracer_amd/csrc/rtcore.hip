@@ -14,6 +14,7 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -408,6 +409,19 @@ extern "C" int rt_debug_sort_keys(rt_ctx *ctx, const uint32_t *keys, uint32_t n,
     if (n == 0) return RT_OK;
     int rc = ctx_set_device(ctx);
     if (rc != RT_OK) return rc;
+    // the order is defined by the top `bits` bits alone: the sort may run over the whole word
+    // (sort.hip), so the other bits are cleared in the copy that is sorted
+    std::vector<uint32_t> masked;
+    if (bits < 32) {
+        try {
+            masked.assign(keys, keys + n);
+        } catch (const std::exception &) {
+            return fail(RT_ERR_NOMEM, "rt_debug_sort_keys: out of host memory");
+        }
+        const uint32_t mask = 0xFFFFFFFFu << (32u - bits);
+        for (uint32_t &k : masked) k &= mask;
+        keys = masked.data();
+    }
     DevBuf k_in, k_out, p_out, temp;
     size_t tb = sort_temp_bytes(n, 32u - bits, 32u);
     if (tb == 0) return fail(RT_ERR_HIP, "radix sort temporary-storage query failed");
@@ -471,6 +485,16 @@ extern "C" int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2])
 // ------------------------------------------------------------------------
 // scene
 
+// A NaN or infinite coordinate makes every binning decision of the builder meaningless (the
+// reference would index outside its bucket array and panic, src/bvh/build.rs:118-120); meshes are
+// checked once here.  Returns the index of the first such float, or -1.
+static long long first_non_finite(const float *positions, uint32_t num_vertices)
+{
+    for (size_t i = 0; i < (size_t)num_vertices * 3; i++)
+        if (!std::isfinite(positions[i])) return (long long)i;
+    return -1;
+}
+
 // Device form of the canonical flat tree: same node order, leaf references
 // packed as device_layout.h describes.  Returns the root reference.
 static uint32_t make_dev_nodes(const rt_flat_node *nodes, size_t nn, uint32_t root_ref, uint32_t root_count,
@@ -497,6 +521,9 @@ static uint32_t make_dev_nodes(const rt_flat_node *nodes, size_t nn, uint32_t ro
     return pack_ref(root_ref, root_count);
 }
 
+static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint32_t num_vertices,
+                         const uint32_t *indices, uint32_t num_triangles, const float *geom_normals);
+
 extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num_vertices,
                                const uint32_t *indices, uint32_t num_triangles, const float *geom_normals,
                                rt_scene **out)
@@ -513,6 +540,8 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
         if (indices[i] >= num_vertices)
             return fail(RT_ERR_INVALID, "rt_scene_create: index %u at %zu out of range (%u vertices)", indices[i],
                         i, num_vertices);
+    if (const long long bad = first_non_finite(positions, num_vertices); bad >= 0)
+        return fail(RT_ERR_INVALID, "rt_scene_create: vertex %lld has a NaN or infinite coordinate", bad / 3);
     int rc = ctx_set_device(ctx);
     if (rc != RT_OK) return rc;
 
@@ -520,23 +549,40 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     if (!sc) return fail(RT_ERR_NOMEM, "rt_scene_create: out of host memory");
     sc->ctx = ctx;
     sc->num_triangles = num_triangles;
+    // Everything below allocates and starts threads on the host; nothing of it may leave through
+    // the C ABI as an exception.
+    try {
+        rc = scene_prepare(ctx, sc, positions, num_vertices, indices, num_triangles, geom_normals);
+    } catch (const std::invalid_argument &ex) {
+        rc = fail(RT_ERR_INVALID, "rt_scene_create: %s", ex.what());
+    } catch (const std::exception &ex) {
+        rc = fail(RT_ERR_NOMEM, "rt_scene_create: scene preparation failed: %s", ex.what());
+    }
+    if (rc != RT_OK) {
+        rt_scene_destroy(sc);
+        return rc;
+    }
+    *out = sc;
+    return RT_OK;
+}
+
+// Host-side half of rt_scene_create: both trees, their device images, the upload.  May throw
+// (std::bad_alloc, std::system_error from the builder's threads, std::invalid_argument for a mesh
+// the binning cannot split); returns an RT_ERR_* code for everything else.
+static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint32_t num_vertices,
+                         const uint32_t *indices, uint32_t num_triangles, const float *geom_normals)
+{
+    int rc = RT_OK;
     unsigned hw = std::thread::hardware_concurrency();
     unsigned threads = hw ? std::min(hw, 16u) : 4u;
     if (const char *env = getenv("RTCORE_BUILD_THREADS")) {
         int v = atoi(env);
         if (v >= 1 && v <= 256) threads = (unsigned)v;
     }
-    try {
-        build_bvh(positions, num_vertices, indices, num_triangles, threads, sc->host);
-    } catch (const std::exception &ex) {
-        delete sc;
-        return fail(RT_ERR_NOMEM, "rt_scene_create: BVH build failed: %s", ex.what());
-    }
+    build_bvh(positions, num_vertices, indices, num_triangles, threads, sc->host);
     const HostBvh &hb = sc->host;
-    if (hb.stats.max_depth > 1024) {
-        delete sc;
+    if (hb.stats.max_depth > 1024)
         return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth %u beyond the supported 1024", hb.stats.max_depth);
-    }
 
     // device images
     std::vector<BigLeaf> big;
@@ -625,10 +671,7 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     // Wide walk: up to three deferred children per wide level.
     sc->stack_bound = std::max(std::max(hb.stats.max_depth, fast_depth + extra_depth), 3u * wide_depth) + 1u;
     if (rc == RT_OK) rc = ensure_overflow(ctx, sc->stack_bound);
-    if (rc != RT_OK) {
-        rt_scene_destroy(sc);
-        return rc;
-    }
+    if (rc != RT_OK) return rc;
     {
         float lo[3] = {positions[0], positions[1], positions[2]}, hi[3] = {positions[0], positions[1], positions[2]};
         for (uint32_t v = 1; v < num_vertices; v++)
@@ -655,7 +698,6 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
     sc->dev.xmax_depth = fast_depth + extra_depth;
     sc->dev.wroot_ref = wroot;
     sc->dev.max_depth = hb.stats.max_depth;
-    *out = sc;
     return RT_OK;
 }
 
@@ -669,6 +711,8 @@ static int bvh_build_host_impl(const char *who, const float *positions, uint32_t
     for (size_t i = 0; i < (size_t)num_triangles * 3; i++)
         if (indices[i] >= num_vertices)
             return fail(RT_ERR_INVALID, "%s: index %u at %zu out of range", who, indices[i], i);
+    if (const long long bad = first_non_finite(positions, num_vertices); bad >= 0)
+        return fail(RT_ERR_INVALID, "%s: vertex %lld has a NaN or infinite coordinate", who, bad / 3);
     if (threads == 0) {
         unsigned hw = std::thread::hardware_concurrency();
         threads = hw ? std::min(hw, 16u) : 4u;
@@ -676,6 +720,8 @@ static int bvh_build_host_impl(const char *who, const float *positions, uint32_t
     HostBvh hb;
     try {
         build_bvh(positions, num_vertices, indices, num_triangles, threads, hb, tuning);
+    } catch (const std::invalid_argument &ex) {
+        return fail(RT_ERR_INVALID, "%s: %s", who, ex.what());
     } catch (const std::exception &ex) {
         return fail(RT_ERR_NOMEM, "%s: %s", who, ex.what());
     }
@@ -763,6 +809,8 @@ extern "C" int rt_bvh_refine_host(const float *positions, uint32_t num_vertices,
         if (indices[i] >= num_vertices) return fail(RT_ERR_INVALID, "rt_bvh_refine_host: index out of range");
     for (uint32_t i = 0; i < num_triangles; i++)
         if (order[i] >= num_triangles) return fail(RT_ERR_INVALID, "rt_bvh_refine_host: order[%u] out of range", i);
+    if (const long long bad = first_non_finite(positions, num_vertices); bad >= 0)
+        return fail(RT_ERR_INVALID, "rt_bvh_refine_host: vertex %lld has a NaN or infinite coordinate", bad / 3);
     try {
         std::vector<DevNode> dn, xdn;
         std::vector<BigLeaf> big;

@@ -299,11 +299,34 @@ std::string fmt_duration(double s)
 // Checkpoint of a frame in progress: the float4 accumulation buffer (sums of r, g, b and of sample
 // counts, src/main.rs:108) with the frame parameters the sums depend on.  Random numbers are keyed by
 // (seed, pixel, sample), so continuing at `samples_done` gives the frame an uninterrupted run gives.
+// `frame_hash` covers what else decides a sample's value: the mesh (positions after the scene
+// transform, indices), camera, light and whether the exact traversal forms are used.
 struct CheckpointHeader {
-    char magic[8]; // "RTACCUM1"
-    uint32_t width, height, samples_done, max_bounces, tile_size, reserved;
+    char magic[8]; // "RTACCUM2"
+    uint32_t width, height, samples_done, max_bounces, tile_size, exact;
     uint64_t seed;
+    uint64_t frame_hash;
 };
+
+uint64_t fnv1a(uint64_t h, const void *data, size_t bytes)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < bytes; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
+
+uint64_t frame_hash_of(uint64_t mesh_fingerprint, const rt_camera &cam, const rt_light &light)
+{
+    uint64_t h = 0xCBF29CE484222325ull;
+    h = fnv1a(h, &mesh_fingerprint, sizeof mesh_fingerprint);
+    h = fnv1a(h, cam.eye, sizeof cam.eye);
+    h = fnv1a(h, cam.target, sizeof cam.target);
+    h = fnv1a(h, cam.up, sizeof cam.up);
+    h = fnv1a(h, &cam.fov_deg, sizeof cam.fov_deg);
+    h = fnv1a(h, light.pos, sizeof light.pos);
+    h = fnv1a(h, light.intensity, sizeof light.intensity);
+    return h;
+}
 
 bool write_checkpoint(const std::string &path, const CheckpointHeader &h, const std::vector<float> &accum)
 {
@@ -315,8 +338,10 @@ bool write_checkpoint(const std::string &path, const CheckpointHeader &h, const 
     return ok && rename(tmp.c_str(), path.c_str()) == 0;
 }
 
-// 1 = loaded, 0 = no file, -1 = a file that does not belong to this frame
-int read_checkpoint(const std::string &path, const CheckpointHeader &want, std::vector<float> &accum, uint32_t &samples_done)
+// 1 = loaded, 0 = no file, -1 = a file that does not belong to this frame, -2 = a checkpoint of this
+// frame that holds more samples than `max_samples`
+int read_checkpoint(const std::string &path, const CheckpointHeader &want, uint32_t max_samples, std::vector<float> &accum,
+                    uint32_t &samples_done)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return 0;
@@ -324,9 +349,11 @@ int read_checkpoint(const std::string &path, const CheckpointHeader &want, std::
     std::vector<float> data(accum.size());
     bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, want.magic, 8) == 0 && h.width == want.width &&
               h.height == want.height && h.max_bounces == want.max_bounces && h.tile_size == want.tile_size &&
-              h.seed == want.seed && fread(data.data(), sizeof(float), data.size(), f) == data.size();
+              h.exact == want.exact && h.seed == want.seed && h.frame_hash == want.frame_hash &&
+              fread(data.data(), sizeof(float), data.size(), f) == data.size();
     fclose(f);
     if (!ok) return -1;
+    if (h.samples_done > max_samples) return -2;
     accum.swap(data);
     samples_done = h.samples_done;
     return 1;
@@ -415,13 +442,21 @@ int main(int argc, char **argv)
 
     std::vector<float> accum((size_t)args.width * args.height * 4, 0.f);
     rt_trace_stats stats{};
-    CheckpointHeader ck{{'R', 'T', 'A', 'C', 'C', 'U', 'M', '1'}, args.width, args.height, 0, args.max_bounces,
-                        args.tile_size, 0, args.seed};
+    CheckpointHeader ck{{'R', 'T', 'A', 'C', 'C', 'U', 'M', '2'}, args.width, args.height, 0, args.max_bounces,
+                        args.tile_size, args.exact ? 1u : 0u, args.seed,
+                        frame_hash_of(host::mesh_fingerprint(mesh), def.camera, def.light)};
     uint32_t start = 0;
     if (args.resume) {
-        const int r = read_checkpoint(args.checkpoint, ck, accum, start);
+        const int r = read_checkpoint(args.checkpoint, ck, args.samples, accum, start);
+        if (r == -2) {
+            fprintf(stderr, "error: %s already holds more than the %u samples asked for\n", args.checkpoint.c_str(),
+                    args.samples);
+            return 1;
+        }
         if (r < 0) {
-            fprintf(stderr, "error: %s is not a checkpoint of this frame (size, bounces, tile size or seed differ)\n",
+            fprintf(stderr,
+                    "error: %s is not a checkpoint of this frame (size, bounces, tile size, seed, mesh, camera, light "
+                    "or traversal mode differ)\n",
                     args.checkpoint.c_str());
             return 1;
         }

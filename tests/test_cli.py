@@ -156,10 +156,17 @@ def test_cli_checkpoint_resume_gives_the_uninterrupted_frame(scenes, tmp_path):
     assert run(*common, "--output", whole).returncode == 0
     first = run(*common, "--output", part, "--checkpoint", ck, "--stop-after", "4", "--preview")
     assert first.returncode == 0, first.stderr
-    assert os.path.getsize(ck) == 40 + 80 * 48 * 16
+    assert os.path.getsize(ck) == 48 + 80 * 48 * 16
     assert not np.array_equal(read_ppm(part), read_ppm(whole))          # 4 of 6 samples
-    other_seed = run(*common, "--output", part, "--checkpoint", ck, "--resume", "--seed", "7")
-    assert other_seed.returncode == 1 and "not a checkpoint of this frame" in other_seed.stderr
+    # a checkpoint is only continued by the frame it belongs to: seed, camera, light, traversal mode
+    # and mesh all decide what a sample is worth
+    other_mesh = str(tmp_path / "other.obj")
+    scenes.write_obj(scenes.load("test-mesh", n_tris=200, seed=3), other_mesh)
+    for change in (["--seed", "7"], ["--fov", "50.0"], ["--light-power", "1.5"], ["--exact"], ["--scene", other_mesh]):
+        other = run(*common, *change, "--output", part, "--checkpoint", ck, "--resume")
+        assert other.returncode == 1 and "not a checkpoint of this frame" in other.stderr, change
+    fewer = run(*common, "-n", "2", "--output", part, "--checkpoint", ck, "--resume")
+    assert fewer.returncode == 1 and "already holds more" in fewer.stderr
     second = run(*common, "--output", part, "--checkpoint", ck, "--resume", "--progress")
     assert second.returncode == 0, second.stderr
     assert "resumed %s at 4/6 samples" % ck in second.stdout and "6/6 samples completed" in second.stdout
