@@ -15,6 +15,7 @@ pub const RT_NO_HIT: u32 = 0xFFFF_FFFF;
 pub const RT_RENDER_VISIT_STATS: u32 = 1;
 pub const RT_SHARD_SAMPLE: c_int = 0;
 pub const RT_SHARD_TILE: c_int = 1;
+pub const RT_LDS_STACK_ENTRIES: u32 = 24;
 
 #[repr(C)]
 pub struct rt_ctx {
@@ -249,6 +250,18 @@ extern "C" {
         n: u32,
         stats: *mut rt_trace_stats,
     ) -> c_int;
+    pub fn rt_intersect1(
+        scene: *mut rt_scene,
+        ray: *mut rt_stream_ray,
+        hit: *mut u32,
+        stats: *mut rt_trace_stats,
+    ) -> c_int;
+    pub fn rt_occluded1(
+        scene: *mut rt_scene,
+        ray: *const rt_stream_ray,
+        occluded: *mut u8,
+        stats: *mut rt_trace_stats,
+    ) -> c_int;
     pub fn rt_occluded_stream_device(
         scene: *mut rt_scene,
         d_rays: *const rt_stream_ray,
@@ -311,6 +324,7 @@ extern "C" {
     pub fn rt_debug_sort_keys(ctx: *mut rt_ctx, keys: *const u32, n: u32, bits: u32, perm: *mut u32) -> c_int;
     pub fn rt_ctx_last_stats_split(ctx: *mut rt_ctx, out: *mut rt_trace_stats) -> c_int;
     pub fn rt_ctx_last_max_ray_steps(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
+    pub fn rt_ctx_last_max_stack_entries(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
 }
 
 // Layout checks against the sizes include/rtcore.h implies.

@@ -62,7 +62,8 @@ impl Context {
     }
 
     /// The reference's exact per-ray walk for every launch (ids, distances and
-    /// visit counters equal to `Bvh::intersect_stream`), about 15-20 % slower.
+    /// visit counters equal to `Bvh::intersect_stream`); frames render at 60-75 % of the
+    /// default configuration's rate.
     pub fn set_exact(&mut self) -> Result<()> {
         self.set_option("traversal_depth0", 0)?;
         self.set_option("traversal_deep", 1)?;
@@ -155,6 +156,25 @@ impl<'c> Scene<'c> {
         }
         add_stats(stats, &st);
         Ok(())
+    }
+
+    /// `Bvh::intersect1` (src/bvh/intersect1.rs:109-210): closest hit of one ray, in that
+    /// function's visit order; `ray.origin_far[3]` is shrunk to the hit distance.
+    pub fn intersect1(&mut self, ray: &mut StreamRay, stats: &mut TraceStats) -> Result<Option<u32>> {
+        let mut hit = sys::RT_NO_HIT;
+        let mut st = TraceStats::default();
+        check(unsafe { sys::rt_intersect1(self.raw, ray, &mut hit, &mut st) })?;
+        add_stats(stats, &st);
+        Ok(if hit == sys::RT_NO_HIT { None } else { Some(hit) })
+    }
+
+    /// `Bvh::occluded1` (src/bvh/intersect1.rs:7-106): any hit of one ray in [near, far).
+    pub fn occluded1(&mut self, ray: &StreamRay, stats: &mut TraceStats) -> Result<bool> {
+        let mut occ = 0u8;
+        let mut st = TraceStats::default();
+        check(unsafe { sys::rt_occluded1(self.raw, ray, &mut occ, &mut st) })?;
+        add_stats(stats, &st);
+        Ok(occ != 0)
     }
 
     /// A whole frame (or one progressive pass: advance `params.sample_offset`)

@@ -157,7 +157,10 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       stream entry points: 0 = while-while loop on the binary tree, 1 = one
  *                       item (node or triangle) per iteration on the binary tree, 2 = one
  *                       item per iteration on the quantized 4-wide tree, 3 = while-while loop
- *                       on the quantized 4-wide tree.  Defaults 3, 2, 1.  Forms 0 and 1 walk
+ *                       on the quantized 4-wide tree.  "traversal_stream" also takes 4 = form 1 in
+ *                       the visit order of the reference's single-ray closest hit
+ *                       (src/bvh/intersect1.rs:109-210: left child first, boxes culled against
+ *                       the far distance the ray arrived with).  Defaults 3, 2, 1.  Forms 0 and 1 walk
  *                       the reference's tree in the reference's order (exact distances, ids
  *                       and visit counters); 2 and 3 walk finer, conservatively quantized
  *                       boxes over the same triangles in another order: same distances except
@@ -303,6 +306,18 @@ int rt_occluded_stream(rt_scene *scene, const rt_stream_ray *rays, uint8_t *occl
 int rt_occluded_stream_device(rt_scene *scene, const rt_stream_ray *d_rays, uint8_t *d_occluded,
                               uint32_t n, rt_trace_stats *stats, void *hip_stream);
 
+/* Bvh::intersect1, src/bvh/intersect1.rs:109-210, and Bvh::occluded1, src/bvh/intersect1.rs:7-106:
+ * one ray.  rt_intersect1 walks in that function's own order -- left child first, boxes culled
+ * against the far distance the ray arrives with, triangles accepted against the shrinking far
+ * -- so its visit counters are that function's, and on an exact-distance tie it returns
+ * the triangle that function returns; *hit = mesh triangle id or RT_NO_HIT and
+ * ray->origin_far[3] is shrunk to the hit distance.  One ray per call keeps one lane of one wave
+ * busy: these exist so that a host written against the single-ray methods links and
+ * gives the same answers; arrays of rays go to the stream entry points (option
+ * "traversal_stream" = 4 gives them this visit order). */
+int rt_intersect1(rt_scene *scene, rt_stream_ray *ray, uint32_t *hit, rt_trace_stats *stats);
+int rt_occluded1(rt_scene *scene, const rt_stream_ray *ray, uint8_t *occluded, rt_trace_stats *stats);
+
 /* The integrator call of src/main.rs:133-161 for a whole frame (all tiles of
  * the shard) instead of one tile: integrate_tile_stream,
  * src/integrators/integrate_stream.rs:56-164, as generate / extend / shade /
@@ -385,6 +400,14 @@ int rt_ctx_last_stats_split(rt_ctx *ctx, rt_trace_stats out[2]);
  * that collected per-visit statistics: out[0] closest-hit, out[1] any-hit.  A
  * kernel cannot end before its longest ray does; this is the tail diagnostic. */
 int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2]);
+
+/* Most deferred nodes any single ray held on its traversal stack at once, same call and split as
+ * rt_ctx_last_max_ray_steps.  The reference's stacks are ArrayVecs of 32 (single ray,
+ * src/bvh/intersect1.rs:12,115) and 64 (stream, src/bvh/intersect_stream.rs:21) entries and panic
+ * beyond that; here the first RT_LDS_STACK_ENTRIES entries of a lane are kept in LDS and deeper
+ * ones in a global overflow area sized from the scene's tree depth, so any depth up to 1024 works. */
+#define RT_LDS_STACK_ENTRIES 24
+int rt_ctx_last_max_stack_entries(rt_ctx *ctx, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

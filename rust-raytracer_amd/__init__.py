@@ -31,6 +31,7 @@ LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(_HERE, "librtcore.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rtcore.h")
 
 NO_HIT = 0xFFFFFFFF
+LDS_STACK_ENTRIES = 24  # RT_LDS_STACK_ENTRIES
 RENDER_VISIT_STATS = 1
 
 RAY_DTYPE = np.dtype([("origin_far", np.float32, 4),
@@ -112,6 +113,7 @@ EXPORTS = {
     "rt_debug_sort_keys": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "rt_ctx_last_launch_ms": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rt_ctx_last_max_ray_steps": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
+    "rt_ctx_last_max_stack_entries": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
     "rt_ctx_last_stats_split": (C.c_int, [_vp, C.POINTER(TraceStats * 2)]),
     "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
@@ -131,6 +133,8 @@ EXPORTS = {
     "rt_intersect_stream_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats), _vp]),
     "rt_occluded_stream": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats)]),
     "rt_occluded_stream_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats), _vp]),
+    "rt_intersect1": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32), C.POINTER(TraceStats)]),
+    "rt_occluded1": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint8), C.POINTER(TraceStats)]),
     "rt_render": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(LightC), C.POINTER(RenderParams), _vp,
                             C.POINTER(TraceStats)]),
     "rt_render_device": (C.c_int, [_vp, C.POINTER(CameraC), C.POINTER(LightC), C.POINTER(RenderParams),
@@ -315,6 +319,11 @@ class Context:
         _check(_lib.rt_ctx_last_max_ray_steps(self.h, C.byref(out)))
         return int(out[0]), int(out[1])
 
+    def last_max_stack_entries(self):
+        out = (C.c_uint64 * 2)()
+        _check(_lib.rt_ctx_last_max_stack_entries(self.h, C.byref(out)))
+        return int(out[0]), int(out[1])
+
     def last_stats_split(self):
         """Counters of the last call with statistics: (closest-hit, any-hit)."""
         out = (TraceStats * 2)()
@@ -394,6 +403,23 @@ class Scene:
         st = TraceStats()
         _check(_lib.rt_occluded_stream(self.h, _p(r), _p(occ), r.shape[0], C.byref(st) if stats else None))
         return occ, (st.as_dict() if stats else None)
+
+    def intersect1(self, ray):
+        """Bvh::intersect1 (src/bvh/intersect1.rs:109-210) on one ray (a length-1 RAY_DTYPE array):
+        (hit id, hit distance, stats dict)."""
+        r = np.ascontiguousarray(ray.copy()).reshape(1)
+        hit = C.c_uint32(NO_HIT)
+        st = TraceStats()
+        _check(_lib.rt_intersect1(self.h, _p(r), C.byref(hit), C.byref(st)))
+        return int(hit.value), np.float32(r["origin_far"][0, 3]), st.as_dict()
+
+    def occluded1(self, ray):
+        """Bvh::occluded1 (src/bvh/intersect1.rs:7-106) on one ray: (bool, stats dict)."""
+        r = np.ascontiguousarray(ray).reshape(1)
+        occ = C.c_uint8(0)
+        st = TraceStats()
+        _check(_lib.rt_occluded1(self.h, _p(r), C.byref(occ), C.byref(st)))
+        return bool(occ.value), st.as_dict()
 
     def render(self, cam, light, width, height, samples, max_bounces=2, tile_size=16, seed=1235468,
                sample_offset=0, shard_index=0, shard_count=1, samples_per_pass=0, accum=None,

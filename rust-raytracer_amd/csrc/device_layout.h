@@ -137,6 +137,7 @@ struct StatsDev {
     unsigned long long leaf_rays;
     unsigned long long obj_intersect;
     unsigned long long max_ray_steps; // most node visits + triangle tests any single ray needed
+    unsigned long long max_stack_entries; // most deferred nodes any single ray held at once
 };
 
 } // namespace rtc

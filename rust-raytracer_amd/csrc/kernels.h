@@ -75,7 +75,8 @@ struct TraceLaunch {
     unsigned min_active; // a wave refills when fewer lanes than this are traversing (1..64)
     unsigned mode;       // 0 = while-while loop, 1 = one item (node or triangle) per iteration,
                          // 2 = one item per iteration on the quantized 4-wide tree, 3 = while-while loop on it
-                         // (no visit counters in 2 and 3)
+                         // (no visit counters in 2 and 3), 4 = form 1 in the visit order of the reference's
+                         // single-ray closest hit (stream entry points only)
     const unsigned *perm; // optional: process ray perm[i] at position i (queue sorted by key), or null
     unsigned perm_n;      // perm covers (and permutes) queue entries 0..perm_n-1
     // stragglers: a ray that has used coop_steps loop iterations is finished by its

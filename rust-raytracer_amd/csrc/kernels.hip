@@ -148,6 +148,7 @@ struct Counters {
     unsigned inner, leaf, tris;
     unsigned ray_start; // inner + tris when the lane's current ray began
     unsigned max_steps; // longest ray this lane has finished
+    unsigned max_sp;    // most stack entries this lane has held at once
 };
 
 // Per-lane traversal stack: the first kLdsDepth entries live in LDS in
@@ -233,6 +234,7 @@ struct LaneState {
     unsigned hit;           // closest: mesh triangle id or ~0u; any-hit: 1 when occluded
     unsigned index;         // position of the ray in its queue
     unsigned steps;         // loop iterations spent on this ray (straggler detection)
+    float far0;             // far distance the ray arrived with (single-ray order only)
     bool have_ray;
 };
 
@@ -250,6 +252,7 @@ __device__ __forceinline__ void lane_begin(LaneState &s, unsigned root_ref, cons
     s.hit = 0xFFFFFFFFu;
     s.index = index;
     s.steps = 0;
+    s.far0 = r.far_t;
     s.have_ray = true;
 }
 
@@ -309,7 +312,10 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
             const bool hs = left_first ? hr : hl;
             if (hf) {
                 cur = first;
-                if (hs) st.push(second);
+                if (hs) {
+                    st.push(second);
+                    if (STATS) cnt.max_sp = (unsigned)st.sp > cnt.max_sp ? (unsigned)st.sp : cnt.max_sp;
+                }
             } else if (hs) {
                 cur = second;
             } else {
@@ -371,7 +377,13 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
 // what starves the while-while form on incoherent rays (a third of the lanes
 // active on San-Miguel-class bounce rays).  The per-ray order of node visits
 // and triangle tests is unchanged, so results and counters are identical.
-template <bool ANYHIT, bool STATS, class STACK>
+//
+// SINGLE = true walks in the order of Bvh::intersect1 (src/bvh/intersect1.rs:109-210) instead:
+// left child first whatever the entry distances (181-191), and boxes culled against the far
+// distance the ray ARRIVED with -- the reference loads its near/far register once before the loop
+// (128-129) -- while triangles are accepted against the shrinking far (198).  Same closest
+// distance; other visit counters, and on an exact-distance tie the triangle found first in that order.
+template <bool ANYHIT, bool STATS, bool SINGLE, class STACK>
 __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s, STACK &st,
                                                Counters &cnt, unsigned min_active, unsigned max_steps)
 {
@@ -429,19 +441,23 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
             const float tfzl = __fmaf_rn(fzl, r.rd.z, -s.ordz), tfzr = __fmaf_rn(fzr, r.rd.z, -s.ordz);
             const float nearl = fmaxf(fmaxf(fmaxf(tnxl, tnyl), tnzl), r.near_t);
             const float nearr = fmaxf(fmaxf(fmaxf(tnxr, tnyr), tnzr), r.near_t);
-            const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), r.far_t);
-            const float farr = fminf(fminf(fminf(tfxr, tfyr), tfzr), r.far_t);
+            const float cull_far = SINGLE ? s.far0 : r.far_t;
+            const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), cull_far);
+            const float farr = fminf(fminf(fminf(tfxr, tfyr), tfzr), cull_far);
             const bool hl = nearl <= farl;
             const bool hr = nearr <= farr;
             const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
-            const bool left_first = ANYHIT ? true : (nearl <= nearr);
+            const bool left_first = (ANYHIT || SINGLE) ? true : (nearl <= nearr);
             const unsigned first = left_first ? left : right;
             const unsigned second = left_first ? right : left;
             const bool hf = left_first ? hl : hr;
             const bool hs = left_first ? hr : hl;
             if (hf) {
                 cur = first;
-                if (hs) st.push(second);
+                if (hs) {
+                    st.push(second);
+                    if (STATS) cnt.max_sp = (unsigned)st.sp > cnt.max_sp ? (unsigned)st.sp : cnt.max_sp;
+                }
             } else if (hs) {
                 cur = second;
             } else {
@@ -1001,13 +1017,16 @@ __device__ __forceinline__ void flush_stats(const Counters &cnt, unsigned long l
     if (!STATS) return;
     unsigned long long a = wave_sum(cnt.inner), b = wave_sum(cnt.leaf), c = wave_sum(cnt.tris),
                        d = wave_sum(rays);
-    unsigned long long m = cnt.max_steps;
+    unsigned long long m = cnt.max_steps, ms = cnt.max_sp;
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_down(m, off);
         m = o > m ? o : m;
+        const unsigned long long os = __shfl_down(ms, off);
+        ms = os > ms ? os : ms;
     }
     if (lane_id() == 0) {
         atomicMax(&stats->max_ray_steps, m);
+        atomicMax(&stats->max_stack_entries, ms);
         atomicAdd(&stats->inner_rays, a);
         atomicAdd(&stats->leaf_rays, b);
         atomicAdd(&stats->obj_intersect, c);
@@ -1147,6 +1166,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
                                                       TraceLaunch tl)
 {
     constexpr int kDepth = TraceTune<ANYHIT, STATS, MODE, IO>::lds_depth;
+    constexpr bool kWide = MODE == 2 || MODE == 3; // forms on the quantized 4-wide tree
     __shared__ unsigned lds_stack[kDepth * kBlock];
     const unsigned n = n_ptr ? *n_ptr : n_val;
     const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
@@ -1155,7 +1175,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
     st.ovf = tl.ovf + gtid;
     st.ovf_stride = gridDim.x * kBlock;
     st.sp = 0;
-    Counters cnt{0, 0, 0, 0, 0};
+    Counters cnt{0, 0, 0, 0, 0, 0};
     unsigned long long nrays = 0;
 
     const unsigned range_len = (n + kFetchRanges - 1u) / kFetchRanges;
@@ -1187,7 +1207,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
                     if (ray >= n) ray = idx; // never index outside the queue, whatever the permutation holds
                 }
                 RayRegs loaded = io.load(ray);
-                if (MODE >= 2) {
+                if (kWide) {
                     // An exactly axis-parallel ray (cosine sampling returns the surface normal once
                     // in 2^24 draws, and floors and walls are axis aligned) has 1/d = +-inf, and
                     // plane*inf - o*inf is +-inf or NaN by the signs of plane and o: with far still
@@ -1202,7 +1222,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
                     const float dz = fabsf(loaded.d.z) < tiny ? copysignf(tiny, loaded.d.z) : loaded.d.z;
                     loaded.rd = v3(1.f / dx, 1.f / dy, 1.f / dz);
                 }
-                lane_begin(s, MODE >= 2 ? sc.wroot_ref : sc.root_ref, loaded, ray);
+                lane_begin(s, kWide ? sc.wroot_ref : sc.root_ref, loaded, ray);
                 st.sp = 0;
                 // A ray with a NaN or infinite origin or direction component cannot be accepted by
                 // the triangle test (its determinant is not finite), but NaN slab distances drop every
@@ -1235,7 +1255,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
         else if (MODE == 2)
             traverse_wide_steps<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else
-            traverse_steps<ANYHIT, STATS>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+            traverse_steps<ANYHIT, STATS, (MODE == 4)>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
 
         // ---- stragglers: rays that used up their step budget are finished by the whole wave
         {
@@ -1244,7 +1264,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
             while (parked != 0) {
                 const unsigned p = (unsigned)__ffsll((long long)parked) - 1u;
-                coop_finish<ANYHIT, STATS, (MODE >= 2)>(sc, s, st, cnt, p, work, tl.coop_cap);
+                coop_finish<ANYHIT, STATS, kWide>(sc, s, st, cnt, p, work, tl.coop_cap);
                 parked &= parked - 1ull;
             }
         }
@@ -1789,7 +1809,7 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
                          hipStream_t stream)
 {
     const unsigned grid = trace_grid(n_upper, max_blocks);
-    if (tl.mode >= 2 && !stats && sc.wnodes) {
+    if ((tl.mode == 2 || tl.mode == 3) && !stats && sc.wnodes) {
         // 4-wide tree, no visit counters in these forms
         if (tl.mode == 2) {
             if (anyhit)
@@ -1805,7 +1825,12 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
     }
     else if (tl.mode == 0)
         launch_trace_mode<0>(anyhit, stats, sc, io, n_ptr, n_val, grid, tl, stream);
-    else
+    else if (tl.mode == 4 && !anyhit) { // the any-hit walk of form 1 already is Bvh::occluded1
+        if (stats)
+            launch_one<false, true, 4, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+        else
+            launch_one<false, false, 4, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+    } else
         launch_trace_mode<1>(anyhit, stats, sc, io, n_ptr, n_val, grid, tl, stream);
 }
 
@@ -1839,7 +1864,7 @@ void launch_extend_primary(const SceneDev &sc, const CameraDev &cam, const PassD
     const PrimaryIO io{cam, ps, hit_ids, hit_t};
     const unsigned n = ps.num_slots;
     const unsigned grid = trace_grid(n, max_blocks);
-    const unsigned mode = (tl.mode >= 2 && !sc.wnodes) ? 1u : tl.mode;
+    const unsigned mode = ((tl.mode >= 2 && !sc.wnodes) || tl.mode > 3) ? 1u : tl.mode;
     switch (mode) {
     case 0:
         launch_one<false, false, 0, PrimaryIO>(sc, io, nullptr, n, grid, tl, stream);

@@ -27,6 +27,8 @@
 
 using namespace rtc;
 
+static_assert(RT_LDS_STACK_ENTRIES == RTC_LDS_STACK_DEPTH, "rtcore.h documents the LDS part of the traversal stack");
+
 // ------------------------------------------------------------------------
 // errors
 
@@ -148,6 +150,7 @@ struct rt_ctx {
     bool timing = true;
     rt_trace_stats last_split[2]{}; // [0] closest-hit launches, [1] any-hit launches of the last call with stats
     uint64_t last_max_steps[2] = {0, 0};
+    uint64_t last_max_stack[2] = {0, 0};
 };
 
 struct rt_scene {
@@ -254,7 +257,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_FUSE_PRIMARY")) ctx->fuse_primary = atoi(env) ? 1u : 0u;
     if (const char *env = getenv("RTCORE_TRAVERSAL_STREAM")) {
         int v = atoi(env);
-        if (v >= 0 && v <= 3) ctx->trav_stream = (unsigned)v;
+        if (v >= 0 && v <= 4) ctx->trav_stream = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
         int v = atoi(env);
@@ -361,7 +364,7 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->fuse_primary = (unsigned)value;
     } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
         ctx->fast_tree_buckets = (unsigned)value;
-    } else if (n == "traversal_stream" && in(0, 3)) {
+    } else if (n == "traversal_stream" && in(0, 4)) {
         ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
         ctx->trav_mode[0] = (unsigned)value;
@@ -479,6 +482,14 @@ extern "C" int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2])
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_max_ray_steps: NULL argument");
     out[0] = ctx->last_max_steps[0];
     out[1] = ctx->last_max_steps[1];
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_last_max_stack_entries(rt_ctx *ctx, uint64_t out[2])
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_max_stack_entries: NULL argument");
+    out[0] = ctx->last_max_stack[0];
+    out[1] = ctx->last_max_stack[1];
     return RT_OK;
 }
 
@@ -919,10 +930,14 @@ static void stats_from_dev(const StatsDev &d, rt_trace_stats *s)
     s->obj_intersect += d.obj_intersect;
 }
 
+constexpr unsigned kModeOfContext = 0xFFFFFFFFu; // trace_stream_device: use the context's "traversal_stream"
+
 static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_rays, uint32_t *d_hits,
-                               uint8_t *d_occ, uint32_t n, rt_trace_stats *stats, hipStream_t s, bool sync_stats)
+                               uint8_t *d_occ, uint32_t n, rt_trace_stats *stats, hipStream_t s, bool sync_stats,
+                               unsigned mode = kModeOfContext)
 {
     rt_ctx *ctx = sc->ctx;
+    if (mode == kModeOfContext) mode = ctx->trav_stream;
     bool want = stats != nullptr;
     if (want) HIP_TRY(hipMemsetAsync(ctx->dstats.p, 0, 2 * sizeof(StatsDev), s));
     size_t slot;
@@ -930,7 +945,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
-                   ctx->min_active[anyhit ? 1 : 0], ctx->trav_stream, nullptr, 0, nullptr, 0, 0};
+                   ctx->min_active[anyhit ? 1 : 0], mode, nullptr, 0, nullptr, 0, 0};
     fill_coop(ctx, sc, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
@@ -943,6 +958,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
         for (int k = 0; k < 2; k++) {
             ctx->last_split[k] = rt_trace_stats{};
             ctx->last_max_steps[k] = h[k].max_ray_steps;
+            ctx->last_max_stack[k] = h[k].max_stack_entries;
             stats_from_dev(h[k], &ctx->last_split[k]);
             stats_from_dev(h[k], stats);
         }
@@ -1014,7 +1030,7 @@ int ensure_host_pipeline(rt_ctx *ctx, uint32_t n)
 
 // Closest-hit (hits != NULL) or any-hit (occluded != NULL) over host rays, chunk by chunk.
 int host_stream_trace(rt_scene *sc, rt_stream_ray *rays, const rt_stream_ray *rays_in, uint32_t *hits, uint8_t *occluded,
-                      uint32_t n, rt_trace_stats *stats)
+                      uint32_t n, rt_trace_stats *stats, unsigned mode = kModeOfContext)
 {
     rt_ctx *ctx = sc->ctx;
     int rc = ctx_set_device(ctx);
@@ -1042,7 +1058,7 @@ int host_stream_trace(rt_scene *sc, rt_stream_ray *rays, const rt_stream_ray *ra
     };
     ctx->used = 0;
     rt_trace_stats total{}, split[2]{};
-    uint64_t max_steps[2] = {0, 0};
+    uint64_t max_steps[2] = {0, 0}, max_stack[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(ctx->chunk_rays[0].p, rays_in, (size_t)count(0) * sizeof(rt_stream_ray), hipMemcpyHostToDevice,
                            single ? s : cs));
     if (!single) HIP_TRY(hipEventRecord(ctx->h2d_done[0], cs));
@@ -1055,13 +1071,14 @@ int host_stream_trace(rt_scene *sc, rt_stream_ray *rays, const rt_stream_ray *ra
         if (!single) HIP_TRY(hipStreamWaitEvent(s, ctx->h2d_done[b], 0));
         rt_trace_stats st{};
         rc = trace_stream_device(sc, anyhit, d_rays, anyhit ? nullptr : d_hits, anyhit ? (uint8_t *)d_hits : nullptr, m,
-                                 stats ? &st : nullptr, s, true);
+                                 stats ? &st : nullptr, s, true, mode);
         if (rc != RT_OK) return rc;
         if (stats) {
             add_stats(total, st);
             for (int q = 0; q < 2; q++) { // the per-kind view of the call is the sum over its chunks
                 add_stats(split[q], ctx->last_split[q]);
                 max_steps[q] = std::max(max_steps[q], ctx->last_max_steps[q]);
+                max_stack[q] = std::max(max_stack[q], ctx->last_max_stack[q]);
             }
         }
         if (!anyhit) launch_gather_far(d_rays, d_far, m, s);
@@ -1089,6 +1106,7 @@ int host_stream_trace(rt_scene *sc, rt_stream_ray *rays, const rt_stream_ray *ra
         for (int q = 0; q < 2; q++) {
             ctx->last_split[q] = split[q];
             ctx->last_max_steps[q] = max_steps[q];
+            ctx->last_max_stack[q] = max_stack[q];
         }
     }
     return RT_OK;
@@ -1112,6 +1130,18 @@ extern "C" int rt_occluded_stream(rt_scene *sc, const rt_stream_ray *rays, uint8
     if (n && (!rays || !occluded)) return fail(RT_ERR_INVALID, "rt_occluded_stream: NULL buffer");
     if (n == 0) return RT_OK;
     return host_stream_trace(sc, nullptr, rays, nullptr, occluded, n, stats);
+}
+
+extern "C" int rt_intersect1(rt_scene *sc, rt_stream_ray *ray, uint32_t *hit, rt_trace_stats *stats)
+{
+    if (!sc || !ray || !hit) return fail(RT_ERR_INVALID, "rt_intersect1: NULL argument");
+    return host_stream_trace(sc, ray, ray, hit, nullptr, 1, stats, 4u);
+}
+
+extern "C" int rt_occluded1(rt_scene *sc, const rt_stream_ray *ray, uint8_t *occluded, rt_trace_stats *stats)
+{
+    if (!sc || !ray || !occluded) return fail(RT_ERR_INVALID, "rt_occluded1: NULL argument");
+    return host_stream_trace(sc, nullptr, ray, nullptr, occluded, 1, stats, 1u);
 }
 
 // ------------------------------------------------------------------------
@@ -1472,6 +1502,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
         for (int q = 0; q < 2; q++) {
             ctx->last_split[q] = rt_trace_stats{};
             ctx->last_max_steps[q] = h[q].max_ray_steps;
+            ctx->last_max_stack[q] = h[q].max_stack_entries;
             if (visit) {
                 stats_from_dev(h[q], &ctx->last_split[q]);
                 stats_from_dev(h[q], stats);

@@ -64,6 +64,44 @@ def test_trace_parity(O, rt, ctx, scenes, name, kw):
     Sg.close()
 
 
+@pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 20000, "seed": 3}), ("sponza-class", {})])
+def test_single_ray_closest_hit(O, rt, ctx, scenes, name, kw):
+    """Bvh::intersect1 (src/bvh/intersect1.rs:109-210): left child first, boxes culled against the far
+    distance the ray arrived with (128-129), triangles accepted against the shrinking far (198).
+    Traversal form 4 walks in that order, so ids (ties included), distances and visit counters are
+    the oracle's intersect1; rt_intersect1 / rt_occluded1 are the per-ray entry points."""
+    sc = scenes.load(name, **kw)
+    So, Sg = both(O, rt, ctx, sc)
+    lo, hi = sc.positions.min(), sc.positions.max()
+    ctx.set_option("traversal_stream", 4)
+    sets = (("primary", O.generate_primary(sc.camera, 160, 90, 2)),
+            ("random", random_rays(O.make_rays, 20000, 11, lo=lo, hi=hi)),
+            ("finite far", random_rays(O.make_rays, 20000, 12, lo=lo, hi=hi, near=1e-5, far=0.35 * float(hi - lo))))
+    for what, rays in sets:
+        io, to, sto = So.intersect1(rays)
+        ig, tg, stg = Sg.intersect_stream(rays)
+        assert np.array_equal(to, tg), what
+        assert np.array_equal(io, ig), what            # same order, same triangle on a tie
+        for k in COUNTERS:
+            assert stg[k] == sto[k], (what, k, stg[k], sto[k])
+        # and the stream order finds the same distances (other ids on ties only)
+        ios, tos, _ = So.intersect_stream(rays)
+        assert_hits_match(ios, tos, ig, tg, what)
+        check_anyhit(O, So, Sg, rays, name + " " + what)   # form 4 any-hit is occluded1 as before
+    rays = sets[0][1]
+    io, to, _ = So.intersect1(rays)
+    oo, _ = So.occluded1(rays)
+    for i in (0, 777, 5000, 14399, 28799):
+        one_o, _, st_o = So.intersect1(rays[i:i + 1])
+        hit, t, st = Sg.intersect1(rays[i:i + 1])
+        assert hit == io[i] and t == to[i]
+        for k in COUNTERS:
+            assert st[k] == st_o[k], k
+        occ, st = Sg.occluded1(rays[i:i + 1])
+        assert occ == bool(oo[i]) and st["total_rays"] == 1
+    Sg.close()
+
+
 def test_adversarial_rays(O, rt, ctx, scenes):
     """Zero direction components make 1/d infinite and bb*inf - o*inf NaN.  The
     GPU's v_max/v_min drop a NaN operand (that axis' constraint); x86

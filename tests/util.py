@@ -44,3 +44,32 @@ def assert_hits_match(ids_a, t_a, ids_b, t_b, what=""):
     assert np.array_equal(none_a, none_b), "%s: hit/miss differs" % what
     diff = ids_a != ids_b
     return int(diff.sum())  # all of these are exact-t ties by the check above
+
+
+def surface_rays(make_rays, rays, ids, t, seed, near=1e-5, far=np.inf):
+    """Bounce-like rays: from the hit points of `rays` (ids/t = their closest hits) in
+    uniformly random directions, with the reference's SHADOW_RAY_NEAR offset."""
+    rng = np.random.default_rng(seed)
+    hit = ids != 0xFFFFFFFF
+    o = rays["origin_far"][hit, :3] + rays["direction"][hit, :3] * t[hit, None]
+    d = rng.normal(size=o.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return make_rays(o.astype(np.float32), d.astype(np.float32), near=near, far=far)
+
+
+def deep_chain_mesh(n=190, ratio=1.5, first=1e-17):
+    """A row of n triangles in the planes x = first * ratio^i, each ratio times larger than the one
+    before (1e-17 .. 1e16: surface areas stay inside the f32 range).  Binned SAH peels the few
+    triangles of the last buckets off the far end per level, so the tree is a chain about n/5 levels
+    deep with the long side on the left (smaller x), and a ray from the origin along (1, 0.5, 0.013)
+    passes through every box beside every triangle: it defers one sibling per level, more than a
+    traversal stack holds in LDS.  (Triangles below x ~ 1e-4 have |det| < f32::EPSILON and are never
+    hit, src/triangle_opt.rs:24-26; their boxes are walked all the same.)"""
+    pos, nrm = [], []
+    for i in range(n):
+        x = np.float32(first) * np.float32(ratio) ** np.float32(i)
+        pos += [[x, 0.1 * x, -x], [x, x, -x], [x, x, x]]
+        nrm.append([-1.0, 0.0, 0.0])
+    pos = np.array(pos, np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return pos, idx, np.array(nrm, np.float32)
