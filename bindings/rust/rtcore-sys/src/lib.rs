@@ -16,6 +16,7 @@ pub const RT_RENDER_VISIT_STATS: u32 = 1;
 pub const RT_SHARD_SAMPLE: c_int = 0;
 pub const RT_SHARD_TILE: c_int = 1;
 pub const RT_LDS_STACK_ENTRIES: u32 = 24;
+pub const RT_STAT_DEPTHS: usize = 8;
 
 #[repr(C)]
 pub struct rt_ctx {
@@ -149,6 +150,14 @@ pub struct rt_shard_plan {
     pub sample_offset: u32,
     pub shard_index: u32,
     pub shard_count: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct rt_depth_stats {
+    pub rays: [u64; RT_STAT_DEPTHS],
+    pub inner_rays: [u64; RT_STAT_DEPTHS],
+    pub obj_intersect: [u64; RT_STAT_DEPTHS],
 }
 
 extern "C" {
@@ -324,6 +333,7 @@ extern "C" {
     pub fn rt_debug_sort_keys(ctx: *mut rt_ctx, keys: *const u32, n: u32, bits: u32, perm: *mut u32) -> c_int;
     pub fn rt_ctx_last_stats_split(ctx: *mut rt_ctx, out: *mut rt_trace_stats) -> c_int;
     pub fn rt_ctx_last_max_ray_steps(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
+    pub fn rt_ctx_last_depth_stats(ctx: *mut rt_ctx, out: *mut rt_depth_stats) -> c_int;
     pub fn rt_ctx_last_max_stack_entries(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
 }
 

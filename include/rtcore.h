@@ -396,6 +396,19 @@ int rt_debug_sort_keys(rt_ctx *ctx, const uint32_t *keys, uint32_t n, uint32_t b
  * rt_trace_stats argument (src/trace_stats.rs keeps one total only). */
 int rt_ctx_last_stats_split(rt_ctx *ctx, rt_trace_stats out[2]);
 
+/* Counters of the most recent rt_render* call that asked for statistics by path depth (0 = camera
+ * rays and their shadow rays), out[0] closest-hit launches, out[1] any-hit launches: rays[d] always;
+ * inner_rays[d] / obj_intersect[d] with RT_RENDER_VISIT_STATS.  Depths from RT_STAT_DEPTHS-1 on
+ * share the last slot.  No reference counterpart (src/trace_stats.rs keeps totals); this is what
+ * a per-kernel roofline needs, since each depth is a launch of its own. */
+#define RT_STAT_DEPTHS 8
+typedef struct rt_depth_stats {
+    uint64_t rays[RT_STAT_DEPTHS];
+    uint64_t inner_rays[RT_STAT_DEPTHS];
+    uint64_t obj_intersect[RT_STAT_DEPTHS];
+} rt_depth_stats;
+int rt_ctx_last_depth_stats(rt_ctx *ctx, rt_depth_stats out[2]);
+
 /* Longest single ray (node visits + triangle tests) of the most recent call
  * that collected per-visit statistics: out[0] closest-hit, out[1] any-hit.  A
  * kernel cannot end before its longest ray does; this is the tail diagnostic. */

@@ -63,6 +63,14 @@ class TraceStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class DepthStats(C.Structure):
+    """rt_depth_stats"""
+    _fields_ = [("rays", C.c_uint64 * 8), ("inner_rays", C.c_uint64 * 8), ("obj_intersect", C.c_uint64 * 8)]
+
+    def as_dict(self):
+        return {n: [int(x) for x in getattr(self, n)] for n, _ in self._fields_}
+
+
 class BvhStats(C.Structure):
     """src/bvh/build.rs:5-11"""
     _fields_ = [(n, C.c_uint32) for n in ("num_leaves", "num_objs", "max_depth", "max_objs")]
@@ -113,6 +121,7 @@ EXPORTS = {
     "rt_debug_sort_keys": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "rt_ctx_last_launch_ms": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rt_ctx_last_max_ray_steps": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
+    "rt_ctx_last_depth_stats": (C.c_int, [_vp, C.POINTER(DepthStats * 2)]),
     "rt_ctx_last_max_stack_entries": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
     "rt_ctx_last_stats_split": (C.c_int, [_vp, C.POINTER(TraceStats * 2)]),
     "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
@@ -318,6 +327,12 @@ class Context:
         out = (C.c_uint64 * 2)()
         _check(_lib.rt_ctx_last_max_ray_steps(self.h, C.byref(out)))
         return int(out[0]), int(out[1])
+
+    def last_depth_stats(self):
+        """Per-depth counters of the last render call with statistics: (closest-hit, any-hit)."""
+        out = (DepthStats * 2)()
+        _check(_lib.rt_ctx_last_depth_stats(self.h, C.byref(out)))
+        return out[0].as_dict(), out[1].as_dict()
 
     def last_max_stack_entries(self):
         out = (C.c_uint64 * 2)()

@@ -138,6 +138,11 @@ struct StatsDev {
     unsigned long long obj_intersect;
     unsigned long long max_ray_steps; // most node visits + triangle tests any single ray needed
     unsigned long long max_stack_entries; // most deferred nodes any single ray held at once
+    // the same sums by path depth of the launch (render calls; depths >= kStatDepths-1 share the last slot)
+    unsigned long long depth_rays[8];
+    unsigned long long depth_inner[8];
+    unsigned long long depth_tris[8];
 };
+constexpr unsigned kStatDepths = 8;
 
 } // namespace rtc

@@ -84,6 +84,7 @@ struct TraceLaunch {
     void *coop;
     unsigned coop_cap;
     unsigned coop_steps; // 0xFFFFFFFF = never
+    unsigned depth;      // path depth the launch belongs to (slot of the per-depth counters)
 };
 
 // StreamRay (src/ray.rs:6-12) as three float4.
@@ -185,7 +186,7 @@ void launch_connect(bool stats, const SceneDev &sc, const QRay *rays, const Shad
 void launch_extend_primary(const SceneDev &sc, const CameraDev &cam, const PassDev &ps, unsigned *hit_ids,
                            float *hit_t, const TraceLaunch &tl, unsigned max_blocks, hipStream_t stream);
 void launch_set_count(unsigned *dst, unsigned value, hipStream_t stream);
-void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream);
+void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, unsigned depth, bool add_total, hipStream_t stream);
 void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,
                      float *rad_r, float *rad_g, float *rad_b, hipStream_t stream);
 void launch_gather_far(const rt_stream_ray_dev *rays, float *far_t, unsigned n, hipStream_t stream);

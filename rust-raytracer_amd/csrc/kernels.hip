@@ -1012,7 +1012,7 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
 }
 
 template <bool STATS>
-__device__ __forceinline__ void flush_stats(const Counters &cnt, unsigned long long rays, StatsDev *stats)
+__device__ __forceinline__ void flush_stats(const Counters &cnt, unsigned long long rays, StatsDev *stats, unsigned depth)
 {
     if (!STATS) return;
     unsigned long long a = wave_sum(cnt.inner), b = wave_sum(cnt.leaf), c = wave_sum(cnt.tris),
@@ -1031,6 +1031,9 @@ __device__ __forceinline__ void flush_stats(const Counters &cnt, unsigned long l
         atomicAdd(&stats->leaf_rays, b);
         atomicAdd(&stats->obj_intersect, c);
         atomicAdd(&stats->total_rays, d);
+        const unsigned slot = depth < kStatDepths ? depth : kStatDepths - 1u;
+        atomicAdd(&stats->depth_inner[slot], a);
+        atomicAdd(&stats->depth_tris[slot], c);
     }
 }
 
@@ -1279,13 +1282,16 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             }
         }
     }
-    flush_stats<STATS>(cnt, nrays, tl.stats);
+    flush_stats<STATS>(cnt, nrays, tl.stats, tl.depth);
 }
 
-// add n to total_rays when per-visit statistics are off
-__global__ void count_rays_kernel(const unsigned *n_ptr, StatsDev *stats)
+// rays of one launch by depth; also into total_rays when per-visit statistics are off (with them on
+// the trace kernel counts the rays it fetched)
+__global__ void count_rays_kernel(const unsigned *n_ptr, StatsDev *stats, unsigned depth, bool add_total)
 {
-    atomicAdd(&stats->total_rays, (unsigned long long)*n_ptr);
+    const unsigned long long n = *n_ptr;
+    if (add_total) atomicAdd(&stats->total_rays, n);
+    atomicAdd(&stats->depth_rays[depth < kStatDepths ? depth : kStatDepths - 1u], n);
 }
 
 // ------------------------------------------------------------------------
@@ -1901,9 +1907,9 @@ void launch_set_count(unsigned *dst, unsigned value, hipStream_t stream)
     hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(1), 0, stream, dst, value);
 }
 
-void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, hipStream_t stream)
+void launch_count_rays(const unsigned *n_ptr, StatsDev *dstats, unsigned depth, bool add_total, hipStream_t stream)
 {
-    hipLaunchKernelGGL(count_rays_kernel, dim3(1), dim3(1), 0, stream, n_ptr, dstats);
+    hipLaunchKernelGGL(count_rays_kernel, dim3(1), dim3(1), 0, stream, n_ptr, dstats, depth, add_total);
 }
 
 void launch_generate(const CameraDev &cam, const PassDev &ps, QRay *rays, PathInfo *infos, unsigned *n_out,

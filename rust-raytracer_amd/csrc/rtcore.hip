@@ -27,6 +27,7 @@
 
 using namespace rtc;
 
+static_assert(RT_STAT_DEPTHS == kStatDepths, "rt_depth_stats mirrors the device counters");
 static_assert(RT_LDS_STACK_ENTRIES == RTC_LDS_STACK_DEPTH, "rtcore.h documents the LDS part of the traversal stack");
 
 // ------------------------------------------------------------------------
@@ -151,6 +152,7 @@ struct rt_ctx {
     rt_trace_stats last_split[2]{}; // [0] closest-hit launches, [1] any-hit launches of the last call with stats
     uint64_t last_max_steps[2] = {0, 0};
     uint64_t last_max_stack[2] = {0, 0};
+    rt_depth_stats last_depth[2]{}; // per path depth, render calls with stats
 };
 
 struct rt_scene {
@@ -482,6 +484,14 @@ extern "C" int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2])
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_max_ray_steps: NULL argument");
     out[0] = ctx->last_max_steps[0];
     out[1] = ctx->last_max_steps[1];
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_last_depth_stats(rt_ctx *ctx, rt_depth_stats out[2])
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_depth_stats: NULL argument");
+    out[0] = ctx->last_depth[0];
+    out[1] = ctx->last_depth[1];
     return RT_OK;
 }
 
@@ -945,7 +955,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
-                   ctx->min_active[anyhit ? 1 : 0], mode, nullptr, 0, nullptr, 0, 0};
+                   ctx->min_active[anyhit ? 1 : 0], mode, nullptr, 0, nullptr, 0, 0, 0};
     fill_coop(ctx, sc, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
@@ -1384,7 +1394,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 0, s, &slot);
                 if (rc != RT_OK) return rc;
                 TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0],
-                                ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, perm_extend_n, nullptr, 0, 0};
+                                ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, perm_extend_n, nullptr, 0, 0, b};
                 fill_coop(ctx, sc, tle);
                 if (fused && b == 0)
                     launch_extend_primary(sc->dev, cam, ps, (uint32_t *)w.hit_ids.p, (float *)w.hit_t.p, tle,
@@ -1394,7 +1404,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                                   ps.num_slots, tle, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
-                if (want && !visit) launch_count_rays(n_ray(b), dstats, s);
+                if (want) launch_count_rays(n_ray(b), dstats, b, !visit, s);
 
                 ShadeArgs a{};
                 a.rays_in = (const QRay *)w.rays[cur].p;
@@ -1471,13 +1481,13 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
                 TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1],
-                                ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, perm_connect_n, nullptr, 0, 0};
+                                ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, perm_connect_n, nullptr, 0, 0, b};
                 fill_coop(ctx, sc, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
                                n_sh(b), ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
-                if (want && !visit) launch_count_rays(n_sh(b), dstats + 1, s);
+                if (want) launch_count_rays(n_sh(b), dstats + 1, b, !visit, s);
                 cur ^= 1;
             }
             rc = timed_begin(ctx, 2, s, &slot);
@@ -1503,6 +1513,11 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             ctx->last_split[q] = rt_trace_stats{};
             ctx->last_max_steps[q] = h[q].max_ray_steps;
             ctx->last_max_stack[q] = h[q].max_stack_entries;
+            for (unsigned d = 0; d < kStatDepths; d++) {
+                ctx->last_depth[q].rays[d] = h[q].depth_rays[d];
+                ctx->last_depth[q].inner_rays[d] = h[q].depth_inner[d];
+                ctx->last_depth[q].obj_intersect[d] = h[q].depth_tris[d];
+            }
             if (visit) {
                 stats_from_dev(h[q], &ctx->last_split[q]);
                 stats_from_dev(h[q], stats);
