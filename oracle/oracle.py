@@ -72,6 +72,28 @@ def build(force=False):
 
 _lib = None
 
+# flags of the baseline build: SURVEY's CPU-baseline recipe (-O3 -march=native, un-fused)
+NATIVE_CFLAGS = ["-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=gnu11", "-pthread"]
+
+
+def build_native(out_dir):
+    """Compiles rt_oracle.c for the CPU this runs on (bench.py's cpu_baseline leg: the committed
+    library targets x86-64-v3 so that it runs on any box).  Returns (path, flags) or (None, reason)."""
+    out = os.path.join(out_dir, "librt_oracle_native.so")
+    cmd = ["gcc"] + NATIVE_CFLAGS + ["-shared", "-o", out, os.path.join(_HERE, "rt_oracle.c"), "-lm", "-lpthread"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError) as e:
+        return None, repr(e)
+    return out, " ".join(NATIVE_CFLAGS)
+
+
+def use_library(path):
+    """Binds another build of the same source (before the first call into the library)."""
+    global _LIB_PATH, _lib
+    _LIB_PATH = path
+    _lib = None
+
 
 def lib():
     global _lib

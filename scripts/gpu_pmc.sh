@@ -13,7 +13,7 @@ while read -r set; do
   i=$((i+1))
   case " ${PASSES:-1 2 3 4 5 6 7 8 9 10 11} " in *" $i "*) ;; *) continue;; esac
   rm -rf $OUT/p$i
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 2 --warmup 0 --workload $WL --no-cpu-baseline ${BENCH_ARGS} > $OUT/p$i.log 2>&1 || { tail -20 $OUT/p$i.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python3 bench.py --steps 2 --warmup 0 --workload $WL --no-cpu-baseline --no-extras ${BENCH_ARGS} > $OUT/p$i.log 2>&1 || { tail -20 $OUT/p$i.log; exit 1; }
   echo "pass $i ok: $set"
 done <<SETS
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU

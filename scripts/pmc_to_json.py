@@ -14,6 +14,7 @@ from collections import defaultdict
 root, workload = sys.argv[1], sys.argv[2]
 CUS, XCDS, SIMDS = 256, 8, 1024
 acc = {"extend": defaultdict(list), "connect": defaultdict(list)}
+by_kernel = defaultdict(lambda: defaultdict(list))  # template instantiation -> counter -> values
 for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
@@ -25,11 +26,24 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.cs
                 continue
             kind = "connect" if args[0] == "true" else "extend"
             acc[kind][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            name = "trace_kernel<%s>" % ",".join(a.replace("rtc::", "") for a in args)
+            by_kernel[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+# rays per launch of each kernel, from the bench line one of the passes printed
+rays_per_launch = {}
+for f in sorted(glob.glob(os.path.join(root, "p*.log"))):
+    for line in open(f, errors="replace"):
+        if line.startswith("{"):
+            try:
+                for rec in json.loads(line).get("kernels", {}).values():
+                    if isinstance(rec, dict) and "kernel" in rec:
+                        rays_per_launch[rec["kernel"]] = rec["rays_per_launch"]
+            except ValueError:
+                pass
 out = {"workload": workload, "source": "rocprofv3 --pmc, one pass per counter set (scripts/gpu_pmc.sh)"}
-for kind, c in acc.items():
+def record(c):
     m = {k: sum(v) / len(v) for k, v in c.items() if v}
     if not m:
-        continue
+        return None
     rec = {"launches_sampled": max(len(v) for v in c.values())}
     if "FETCH_SIZE" in m:
         rec["hbm_read_bytes_per_launch"] = m["FETCH_SIZE"] * 1024.0 * 2.0
@@ -54,5 +68,21 @@ for kind, c in acc.items():
         rec["vector_loads_per_launch"] = m["SQ_INSTS_VMEM_RD"]
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in m and "TCP_TCC_READ_REQ_sum" in m:
         rec["l1_hit_rate"] = 1.0 - m["TCP_TCC_READ_REQ_sum"] / max(1.0, m["TCP_TOTAL_CACHE_ACCESSES_sum"])
-    out[kind] = rec
+    for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+        if k in m:
+            rec[k] = m[k]
+    return rec
+
+
+for kind, c in acc.items():
+    rec = record(c)
+    if rec:
+        out[kind] = rec
+out["kernels"] = {}
+for name, c in sorted(by_kernel.items()):
+    rec = record(c)
+    if rec:
+        if name in rays_per_launch:
+            rec["rays_per_launch"] = rays_per_launch[name]
+        out["kernels"][name] = rec
 print(json.dumps(out, indent=1))
