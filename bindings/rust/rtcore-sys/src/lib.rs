@@ -137,10 +137,11 @@ pub struct rt_wide_node {
 #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_qwide_node {
     pub origin: [f32; 3],
-    pub scale: [f32; 3],
+    pub exps: u32,
+    pub base4: u32,
+    pub meta: u32,
     pub lo: [u32; 3],
     pub hi: [u32; 3],
-    pub child: [u32; 4],
 }
 
 #[repr(C)]
@@ -212,11 +213,15 @@ extern "C" {
         num_nodes: u32,
         root_ref: u32,
         root_count: u32,
+        num_triangles: u32,
         out: *mut rt_wide_node,
         qout: *mut rt_qwide_node,
+        node_unit: *mut u32,
+        slot_unit: *mut u32,
         num_wide: *mut u32,
         wide_root_ref: *mut u32,
         wide_depth: *mut u32,
+        num_units: *mut u32,
     ) -> c_int;
     pub fn rt_bvh_refine_host(
         positions: *const f32,

@@ -234,12 +234,17 @@ int rt_bvh_build_search_host(const float *positions, uint32_t num_vertices, cons
  * slot has lo = +inf, hi = -inf and repeats child[0].  bin = index of the
  * canonical binary node the wide node was collapsed from.
  *
- * rt_qwide_node (64 bytes) is the form the device traverses: the same node
- * with its child boxes on an 8-bit grid, plane = origin[axis] + byte *
- * scale[axis], child i in byte i of lo[axis] / hi[axis], every box rounded
- * outward (by at least 2^-19 of the node's largest coordinate or extent), so a
- * ray that meets an exact child box meets the quantized one.  Unused slots have
- * lo byte 255 and hi byte 0. */
+ * rt_qwide_node (48 bytes) is the form the device traverses: the same node with its child boxes
+ * on an 8-bit grid, plane = origin[axis] + byte * step[axis], where step is the f32 whose bits
+ * 21..30 are the ten-bit field `axis` of exps (an exponent and two mantissa bits), child i
+ * in byte i of lo[axis] / hi[axis], every box rounded outward (by at least 2^-19 of the node's
+ * largest coordinate or extent), so a ray that meets an exact child box meets the quantized one.
+ * Unused slots have lo byte 255 and hi byte 0.  Nodes and triangles of the wide tree share one
+ * array of 16-byte units on the device (three units each); the children of a node -- a node for an
+ * inner child, its 1..3 triangles (48 bytes each, rt_flat_tri) for a leaf child -- are stored back
+ * to back from unit base4 >> 2, and byte i of meta is
+ *     (units from there to child i) << 2 | triangles of child i (0 = inner node),
+ * which makes  base4 + byte i  the traversal reference (unit << 2 | triangles) of child i. */
 typedef struct rt_wide_node {
     float lo[3][4];
     float hi[3][4];
@@ -250,30 +255,38 @@ typedef struct rt_wide_node {
 
 typedef struct rt_qwide_node {
     float origin[3];
-    float scale[3];
+    uint32_t exps;
+    uint32_t base4;
+    uint32_t meta;
     uint32_t lo[3];
     uint32_t hi[3];
-    uint32_t child[4];
 } rt_qwide_node;
 
 /* Derives the 4-wide forms from a canonical flat tree on the host: children of
  * inner children are pulled up, largest surface area first, until a node has
  * four; the children of a wide node are then ordered largest box first (the
- * order in which the any-hit walk visits hit children).  out and qout may be NULL and otherwise hold num_nodes entries each
- * (the wide tree never has more nodes than the binary one); nodes are written
- * in depth-first pre-order.  wide_root_ref is 0, or the leaf reference when the
- * root is a leaf.  rt_scene_create runs the same code. */
+ * order in which the any-hit walk visits hit children).  out and qout may be NULL and otherwise
+ * hold num_nodes entries each (the wide tree never has more nodes than the binary one); nodes are
+ * written in depth-first pre-order.  wide_root_ref is 0, or the leaf reference when the
+ * root is a leaf.  The device form (qout, and where its items go: node_unit[i] = first unit of
+ * wide node i, slot_unit[s] = first unit of the triangle in leaf slot s, *num_units = units in
+ * all; each may be NULL) needs every leaf to hold at most 3 triangles of [0, num_triangles):
+ * pass the output of rt_bvh_refine_host (max_tris <= 3) or of rt_bvh_build_search_host
+ * (max_leaf <= 3), otherwise RT_ERR_INVALID.  rt_scene_create runs the same code. */
 int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref, uint32_t root_count,
-                     rt_wide_node *out, rt_qwide_node *qout, uint32_t *num_wide, uint32_t *wide_root_ref,
-                     uint32_t *wide_depth);
+                     uint32_t num_triangles, rt_wide_node *out, rt_qwide_node *qout, uint32_t *node_unit,
+                     uint32_t *slot_unit, uint32_t *num_wide, uint32_t *wide_root_ref, uint32_t *wide_depth,
+                     uint32_t *num_units);
 
 /* Finer leaves for the wide tree (no reference counterpart; the reference stops
  * at 8 triangles per leaf, src/bvh/build.rs:80-81).  Takes the canonical flat
  * tree and leaf order of rt_bvh_build_host and returns a copy in which every
- * leaf of 2..8 triangles holding more than max_tris is replaced by a small
+ * leaf holding more than max_tris triangles is replaced by a small
  * binary subtree over its own triangles (ordered by centroid on the leaf's
  * largest centroid-extent axis, cut where area(A)*|A| + area(B)*|B| is least;
- * child boxes are the exact unions of the triangles' vertex bounds).  The
+ * leaves of more than 8 triangles or without a centroid extent, the work of
+ * src/bvh/build.rs:93-101, are cut in halves by slot; child boxes are the
+ * exact unions of the triangles' vertex bounds).  The
  * original nodes keep their indices, new nodes are appended; xorder is a
  * permutation of order that only moves triangles inside their reference leaf.
  * xnodes must hold num_nodes + num_triangles entries, xorder num_triangles.

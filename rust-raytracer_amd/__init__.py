@@ -42,8 +42,8 @@ NODE_DTYPE = np.dtype([("bx", np.float32, 4), ("by", np.float32, 4), ("bz", np.f
                        ("left_count", np.uint32), ("right_count", np.uint32)])
 WIDE_DTYPE = np.dtype([("lo", np.float32, (3, 4)), ("hi", np.float32, (3, 4)), ("child", np.uint32, 4),
                        ("bin", np.uint32), ("pad", np.uint32, 3)])
-QWIDE_DTYPE = np.dtype([("origin", np.float32, 3), ("scale", np.float32, 3), ("lo", np.uint32, 3),
-                        ("hi", np.uint32, 3), ("child", np.uint32, 4)])
+QWIDE_DTYPE = np.dtype([("origin", np.float32, 3), ("exps", np.uint32), ("base4", np.uint32), ("meta", np.uint32),
+                        ("lo", np.uint32, 3), ("hi", np.uint32, 3)])
 TRI_DTYPE = np.dtype([("v0", np.float32, 3), ("v0v1", np.float32, 3), ("v0v2", np.float32, 3),
                       ("id", np.uint32), ("pad", np.uint32, 2)])
 
@@ -130,8 +130,9 @@ EXPORTS = {
                                            C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
     "rt_bvh_build_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
                                     C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
-    "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32),
-                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32)]),
     "rt_bvh_refine_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp,
                                      C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -228,16 +229,27 @@ def build_bvh_search_host(positions, indices, buckets=32, max_leaf=3, threads=0)
     return nodes[:inf["num_inner_nodes"]].copy(), order, inf, st.as_dict()
 
 
-def wide_bvh_host(nodes, root_ref, root_count):
-    """rt_bvh_wide_host: 4-wide forms of a canonical flat tree ->
-    (exact wide nodes, quantized wide nodes, wide root ref, wide depth)."""
+def wide_bvh_host(nodes, root_ref, root_count, num_triangles=None):
+    """rt_bvh_wide_host: 4-wide forms of a canonical flat tree.
+
+    Without num_triangles: (exact wide nodes, wide root ref, wide depth).  With it (the tree must
+    have leaves of at most 3 triangles): (exact wide nodes, quantized 48-byte nodes, first unit of
+    every node, first unit of every leaf slot, units in all, wide root ref, wide depth)."""
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     out = np.zeros(max(len(nodes), 1), dtype=WIDE_DTYPE)
+    n, root, depth, units = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if num_triangles is None:
+        _check(_lib.rt_bvh_wide_host(_p(nodes), len(nodes), int(root_ref), int(root_count), 0, _p(out), None, None,
+                                     None, C.byref(n), C.byref(root), C.byref(depth), None))
+        return out[:n.value].copy(), int(root.value), int(depth.value)
     qout = np.zeros(max(len(nodes), 1), dtype=QWIDE_DTYPE)
-    n, root, depth = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    _check(_lib.rt_bvh_wide_host(_p(nodes), len(nodes), int(root_ref), int(root_count), _p(out), _p(qout),
-                                 C.byref(n), C.byref(root), C.byref(depth)))
-    return out[:n.value].copy(), qout[:n.value].copy(), int(root.value), int(depth.value)
+    node_unit = np.zeros(max(len(nodes), 1), dtype=np.uint32)
+    slot_unit = np.zeros(max(int(num_triangles), 1), dtype=np.uint32)
+    _check(_lib.rt_bvh_wide_host(_p(nodes), len(nodes), int(root_ref), int(root_count), int(num_triangles), _p(out),
+                                 _p(qout), _p(node_unit), _p(slot_unit), C.byref(n), C.byref(root), C.byref(depth),
+                                 C.byref(units)))
+    return (out[:n.value].copy(), qout[:n.value].copy(), node_unit[:n.value].copy(), slot_unit[:int(num_triangles)].copy(),
+            int(units.value), int(root.value), int(depth.value))
 
 
 def refine_bvh_host(positions, indices, nodes, root_ref, root_count, order, max_tris=3):

@@ -49,23 +49,36 @@ struct alignas(128) DevWideNode {
 };
 static_assert(sizeof(DevWideNode) == 128, "DevWideNode must be 128 bytes");
 
-// DevQWideNode (64 bytes) is what the traversal reads: the four child boxes on an
-// 8-bit grid local to the node, plane = origin[axis] + byte * scale[axis], each
-// box rounded OUTWARD by at least the margin the builder documents.  A ray that
-// meets an exact child box therefore meets its quantized box, so the leaves
-// reached are a superset of those of the exact tree and the triangle tests
-// decide the hit as before.  Byte i of every lo/hi word belongs to child i.  An
-// unused slot has lo = 255, hi = 0 on every axis (scale > 0 always, so near >
-// far) and repeats the reference of slot 0, so that even a ray whose slab test
-// degenerates to NaN on every axis only re-tests triangles it has already seen.
-struct alignas(64) DevQWideNode {
+// DevQNode (48 bytes) is what the traversal reads: the four child boxes on an 8-bit grid local to
+// the node, plane = origin[axis] + byte * step[axis], each box rounded OUTWARD by at
+// least the margin the builder documents.  A ray that meets an exact child box therefore meets its
+// quantized box, so the leaves reached are a superset of those of the exact tree and the triangle
+// tests decide the hit as before.  Byte i of every lo/hi word belongs to child i.
+//
+// Nodes and triangles of the wide tree live in ONE array of 16-byte units (a node and a triangle
+// are three units each, so every traversal item is three 16-byte loads).  The children of a node
+// are stored back to back in one block -- a 48-byte node for an inner child, its 1..3 triangles for
+// a leaf child -- and the node holds the block's first unit and one byte per child:
+//     meta byte i = (units from the block start to child i) << 2 | triangles of child i (0 = inner)
+// so that the traversal reference of child i is  base4 + byte i  =  unit << 2 | triangles.
+// An unused slot has lo = 255, hi = 0 on every axis (the grid step is > 0, so near > far) and
+// repeats the meta byte of slot 0, so that even a ray whose slab test degenerates to NaN on every
+// axis only re-tests triangles it has already seen.
+struct alignas(16) DevQNode {
     float origin[3];
-    float scale[3];
+    uint32_t exps;  // grid steps, ten bits per axis (x | y << 10 | z << 20): the top ten bits of a positive
+                    // f32 below its sign, i.e. step = 2^(e - 127) * (1 + m / 4) for field e << 2 | m
+    uint32_t base4; // first unit of the children block << 2
+    uint32_t meta;
     uint32_t lo[3]; // [axis], child i in byte i
     uint32_t hi[3];
-    uint32_t child[4];
 };
-static_assert(sizeof(DevQWideNode) == 64, "DevQWideNode must be 64 bytes");
+static_assert(sizeof(DevQNode) == 48, "DevQNode must be 48 bytes");
+struct alignas(16) Unit {
+    uint32_t w[4];
+};
+constexpr uint32_t kWideLeafTris = 3;  // most triangles a leaf of the wide tree holds (two bits of a reference)
+constexpr uint32_t kUnitsPerItem = 3;  // 16-byte units of a node or a triangle
 
 // 48-byte triangle in leaf order: TriangleOpt {v0v1, v0v2, v0}
 // (src/triangle_opt.rs:10-14) read as three float4, with the mesh triangle id
@@ -118,16 +131,12 @@ struct SceneDev {
     const float *normals; // float4 per mesh triangle (xyz, 0)
     uint32_t root_ref;
     uint32_t max_depth;
-    // 4-wide quantized form of the same tree (optional fast traversal), null when absent.
-    // It is built over the refined binary tree `xnodes` (the reference's tree with its larger
-    // leaves split further) and that tree's leaf order `xtris`; `nodes`/`tris` above stay the
-    // reference's tree for the exact forms.
-    const DevQWideNode *wnodes;
-    const uint32_t *wbin; // per wide node: the node of `xnodes` it was collapsed from
-    const DevNode *xnodes;
-    const DevTri *xtris;
-    uint32_t wroot_ref;
-    uint32_t xmax_depth;
+    // 4-wide quantized tree over the same triangles (the fast traversal forms), null when absent:
+    // DevQNode and DevTri items in one array of 16-byte units, see DevQNode.  `nodes`/`tris`
+    // above stay the reference's tree for the exact forms.
+    const Unit *witems;
+    uint32_t wroot_ref;   // unit << 2 | triangles (a leaf when the mesh has at most kWideLeafTris triangles)
+    uint32_t wmax_depth;  // inner levels of the wide tree
 };
 
 // Counters of src/trace_stats.rs:4-12 as kept on the device.

@@ -53,6 +53,13 @@
 #else
 #define RTC_MIN_LDS_STACK_DEPTH RTC_LDS_STACK_DEPTH
 #endif
+// the two-rays-per-lane form: waves per SIMD it is built for, LDS stack entries per ray
+#ifndef RTC_DUAL_WAVES_PER_SIMD
+#define RTC_DUAL_WAVES_PER_SIMD 4
+#endif
+#ifndef RTC_DUAL_LDS_STACK_DEPTH
+#define RTC_DUAL_LDS_STACK_DEPTH 12
+#endif
 #ifndef RTC_TRACE_WAVES_PER_SIMD
 #define RTC_TRACE_WAVES_PER_SIMD 5
 #endif

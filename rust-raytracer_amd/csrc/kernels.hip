@@ -188,6 +188,18 @@ struct Stack {
         if (sp < LDS_DEPTH) return lds[sp * BLOCK];
         return ovf[(size_t)(sp - LDS_DEPTH) * ovf_stride];
     }
+    // pop() whose (rare) read of the overflow area waits for itself.  A load the compiler can see would
+    // make it wait for every vector memory operation at the point where the paths join -- also for
+    // gathers that are meant to stay in flight across this call.
+    __device__ __forceinline__ unsigned pop_isolated()
+    {
+        sp--;
+        if (sp < LDS_DEPTH) return lds[sp * BLOCK];
+        unsigned v;
+        const unsigned *p = ovf + (size_t)(sp - LDS_DEPTH) * ovf_stride;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
 };
 
 // Moeller-Trumbore of src/triangle_opt.rs:19-42: no back-face cull, |det| <
@@ -516,27 +528,19 @@ __device__ __forceinline__ float vmin3(float a, float b, float c)
     return r;
 }
 
-// The four 16-byte loads of one traversal item as exactly four vector memory
-// instructions: bytes 0..47 for every active lane (node or triangle), bytes
-// 48..63 only for the lanes of `node_mask`.  Written out because the compiler
-// trims the third load to the 8 bytes a triangle needs and then covers the rest
-// of a node with two more instructions, and the instruction count is what the
+// The three 16-byte loads of one traversal item (a node or a triangle of the wide tree, 48 bytes)
+// as exactly three vector memory instructions, written out so that the compiler neither trims the
+// third load to the bytes one kind of item needs nor splits it: the instruction count is what the
 // kernel is bound by.
-__device__ __forceinline__ void load_item(const float4 *p, unsigned long long node_mask, float4 &a0, float4 &a1,
-                                          float4 &a2, uint4 &a3)
+__device__ __forceinline__ void load_item(const float4 *p, float4 &a0, float4 &a1, float4 &a2)
 {
-    unsigned long long saved;
-    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
-                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
-                 "s_mov_b64 %4, exec\n\t"
-                 "s_and_b64 exec, exec, %6\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
-                 "s_mov_b64 exec, %4\n\t"
+    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&s"(saved)
-                 : "v"(p), "s"(node_mask)
-                 : "memory", "scc");
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2)
+                 : "v"(p)
+                 : "memory");
 }
 
 // 64 bytes through the scalar cache into SGPRs: used when every active lane of
@@ -555,94 +559,113 @@ __device__ __forceinline__ float4 f4_of(const u32x16 &n, int i)
                        __uint_as_float(n[i + 3]));
 }
 
-// compare-exchange of two (entry distance, child reference) pairs
-#define RTC_CE(ka, ca, kb, cb)                  \
+// compare-exchange of two packed (entry distance, slot) keys
+#define RTC_CE(ka, kb)                          \
     {                                           \
-        const bool sw_ = kb < ka;               \
-        const float kt_ = sw_ ? kb : ka;        \
-        const unsigned ct_ = sw_ ? cb : ca;     \
-        kb = sw_ ? ka : kb;                     \
-        cb = sw_ ? ca : cb;                     \
-        ka = kt_;                               \
-        ca = ct_;                               \
+        const unsigned lo_ = ka < kb ? ka : kb; \
+        kb = ka < kb ? kb : ka;                 \
+        ka = lo_;                               \
     }
 
-// One quantized wide node: tests the four child boxes, moves `cur` to the first
-// child to visit and defers the others; returns true when no child is hit (the
-// caller pops).
-template <bool ANYHIT, class STACK>
-__device__ __forceinline__ bool qwide_step(const float4 a0, const float4 a1, const float4 a2, const uint4 ch,
-                                           const LaneState &s, STACK &st, unsigned &cur)
+constexpr unsigned kMissKey = 0xFFFFFFFFu;
+
+// traversal reference of the child in slot `slot` (0..3) of a node: base4 + meta byte
+__device__ __forceinline__ unsigned child_ref(unsigned base4, unsigned meta, unsigned slot)
 {
-    const RayRegs &r = s.r;
-    const float inf = __builtin_inff();
-    // a0 = origin.xyz, scale.x; a1 = scale.yz, lo.x, lo.y; a2 = lo.z, hi.x, hi.y, hi.z
+    // v_perm_b32: selector bytes 0..3 pick a byte of `meta`, 0x0c gives 0x00
+    return base4 + __builtin_amdgcn_perm(0u, meta, slot | 0x0C0C0C00u);
+}
+
+// Entry and exit distance of the four child boxes of a quantized node (DevQNode as three 16-byte
+// pieces: a0 = origin.xyz, exps; a1 = base4, meta, lo.x, lo.y; a2 = lo.z, hi.xyz).
+// Child planes are decoded in ray space: t = byte * (step/d) + (origin - o)/d.
+struct SlabRay { // what the box test needs of a ray
+    V3 rd;                  // 1/d
+    float ordx, ordy, ordz; // o * (1/d)
+    bool negx, negy, negz;  // sign bit of 1/d
+};
+__device__ __forceinline__ SlabRay slab_ray(const LaneState &s)
+{
+    return SlabRay{s.r.rd, s.ordx, s.ordy, s.ordz, s.negx, s.negy, s.negz};
+}
+__device__ __forceinline__ SlabRay slab_ray(const RayRegs &r)
+{
+    return SlabRay{r.rd, r.o.x * r.rd.x, r.o.y * r.rd.y, r.o.z * r.rd.z, (__float_as_uint(r.rd.x) >> 31) != 0,
+                   (__float_as_uint(r.rd.y) >> 31) != 0, (__float_as_uint(r.rd.z) >> 31) != 0};
+}
+
+__device__ __forceinline__ void qnode_slabs(const float4 a0, const float4 a1, const float4 a2, const SlabRay &s,
+                                            float near_t, float far_t, float (&n)[4], float (&f)[4])
+{
+    const SlabRay &r = s;
     const unsigned lox = __float_as_uint(a1.z), loy = __float_as_uint(a1.w), loz = __float_as_uint(a2.x);
     const unsigned hix = __float_as_uint(a2.y), hiy = __float_as_uint(a2.z), hiz = __float_as_uint(a2.w);
     const unsigned nxw = s.negx ? hix : lox, fxw = s.negx ? lox : hix;
     const unsigned nyw = s.negy ? hiy : loy, fyw = s.negy ? loy : hiy;
     const unsigned nzw = s.negz ? hiz : loz, fzw = s.negz ? loz : hiz;
-    const float sx = a0.w * r.rd.x, sy = a1.x * r.rd.y, sz = a1.y * r.rd.z;
+    // grid steps: the top ten bits of a positive float each (exponent and two mantissa bits)
+    const unsigned e = __float_as_uint(a0.w);
+    const float gx = __uint_as_float((e << 21) & 0x7FE00000u), gy = __uint_as_float((e << 11) & 0x7FE00000u),
+                gz = __uint_as_float((e << 1) & 0x7FE00000u);
+    const float sx = gx * r.rd.x, sy = gy * r.rd.y, sz = gz * r.rd.z;
     const float bx = __fmaf_rn(a0.x, r.rd.x, -s.ordx), by = __fmaf_rn(a0.y, r.rd.y, -s.ordy),
                 bz = __fmaf_rn(a0.z, r.rd.z, -s.ordz);
 #define RTC_BYTE(w, i) ((float)(((w) >> (8 * (i))) & 0xFFu))
-#define RTC_NEAR(i)                                                                                  \
-        vmax3(__fmaf_rn(RTC_BYTE(nxw, i), sx, bx), __fmaf_rn(RTC_BYTE(nyw, i), sy, by),                  \
-        vmax(__fmaf_rn(RTC_BYTE(nzw, i), sz, bz), r.near_t))
-#define RTC_FAR(i)                                                                                   \
-        vmin3(__fmaf_rn(RTC_BYTE(fxw, i), sx, bx), __fmaf_rn(RTC_BYTE(fyw, i), sy, by),                  \
-        vmin(__fmaf_rn(RTC_BYTE(fzw, i), sz, bz), r.far_t))
-    const float n0 = RTC_NEAR(0), f0 = RTC_FAR(0);
-    const float n1 = RTC_NEAR(1), f1 = RTC_FAR(1);
-    const float n2 = RTC_NEAR(2), f2 = RTC_FAR(2);
-    const float n3 = RTC_NEAR(3), f3 = RTC_FAR(3);
-#undef RTC_NEAR
-#undef RTC_FAR
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        n[i] = vmax3(__fmaf_rn(RTC_BYTE(nxw, i), sx, bx), __fmaf_rn(RTC_BYTE(nyw, i), sy, by),
+                     vmax(__fmaf_rn(RTC_BYTE(nzw, i), sz, bz), near_t));
+        f[i] = vmin3(__fmaf_rn(RTC_BYTE(fxw, i), sx, bx), __fmaf_rn(RTC_BYTE(fyw, i), sy, by),
+                     vmin(__fmaf_rn(RTC_BYTE(fzw, i), sz, bz), far_t));
+    }
 #undef RTC_BYTE
-    float k0 = n0 <= f0 ? n0 : inf;
-    float k1 = n1 <= f1 ? n1 : inf;
-    float k2 = n2 <= f2 ? n2 : inf;
-    float k3 = n3 <= f3 ? n3 : inf;
-    unsigned c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-    if (!ANYHIT || RTC_ANYHIT_SORTED) { // stable 4-input sorting network on the entry distance
-        RTC_CE(k0, c0, k1, c1);
-        RTC_CE(k2, c2, k3, c3);
-        RTC_CE(k0, c0, k2, c2);
-        RTC_CE(k1, c1, k3, c3);
-        RTC_CE(k1, c1, k2, c2);
-        if (k0 < inf) {
-            cur = c0;
-            const int n = (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
-            if (n == 3) st.store(st.sp, c3);
-            if (n >= 2) st.store(st.sp + n - 2, c2);
-            if (n >= 1) st.store(st.sp + n - 1, c1);
-            st.sp += n;
-        } else {
-            return true;
-        }
+}
+
+// One quantized wide node: tests the four child boxes, moves `cur` to the first
+// child to visit and defers the others; returns true when no child is hit (the
+// caller pops).
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ bool qwide_step(const float4 a0, const float4 a1, const float4 a2, const SlabRay &sr,
+                                           float near_t, float far_t, STACK &st, unsigned &cur)
+{
+    float n[4], f[4];
+    qnode_slabs(a0, a1, a2, sr, near_t, far_t, n, f);
+    const unsigned base4 = __float_as_uint(a1.x), meta = __float_as_uint(a1.y);
+    if (!ANYHIT || RTC_ANYHIT_SORTED) {
+        // Hit children nearest first: the entry distance (never negative, so its bits order like an
+        // unsigned) with the slot number in the two lowest mantissa bits, sorted by a 4-input network
+        // of unsigned min/max; ties go to the lower slot.
+        unsigned k0 = n[0] <= f[0] ? (__float_as_uint(n[0]) & ~3u) | 0u : kMissKey;
+        unsigned k1 = n[1] <= f[1] ? (__float_as_uint(n[1]) & ~3u) | 1u : kMissKey;
+        unsigned k2 = n[2] <= f[2] ? (__float_as_uint(n[2]) & ~3u) | 2u : kMissKey;
+        unsigned k3 = n[3] <= f[3] ? (__float_as_uint(n[3]) & ~3u) | 3u : kMissKey;
+        RTC_CE(k0, k1);
+        RTC_CE(k2, k3);
+        RTC_CE(k0, k2);
+        RTC_CE(k1, k3);
+        RTC_CE(k1, k2);
+        if (k0 == kMissKey) return true;
+        cur = child_ref(base4, meta, k0 & 3u);
+        const int m = (k1 != kMissKey ? 1 : 0) + (k2 != kMissKey ? 1 : 0) + (k3 != kMissKey ? 1 : 0);
+        if (m == 3) st.store(st.sp, child_ref(base4, meta, k3 & 3u));
+        if (m >= 2) st.store(st.sp + m - 2, child_ref(base4, meta, k2 & 3u));
+        if (m >= 1) st.store(st.sp + m - 1, child_ref(base4, meta, k1 & 3u));
+        st.sp += m;
+        return false;
     } else {
         // any-hit: the answer does not depend on the order; take the hit children in slot
         // order (src/bvh/intersect1.rs:7-106 goes left first as well)
         unsigned next = kDone;
-        if (k3 < inf) next = c3;
-        if (k2 < inf) {
-            if (next != kDone) st.push(next);
-            next = c2;
-        }
-        if (k1 < inf) {
-            if (next != kDone) st.push(next);
-            next = c1;
-        }
-        if (k0 < inf) {
-            if (next != kDone) st.push(next);
-            next = c0;
-        }
-        if (next != kDone)
-            cur = next;
-        else
-            return true;
+#pragma unroll
+        for (int i = 3; i >= 0; i--)
+            if (n[i] <= f[i]) {
+                if (next != kDone) st.push(next);
+                next = base4 + ((meta >> (8 * i)) & 0xFFu);
+            }
+        if (next == kDone) return true;
+        cur = next;
+        return false;
     }
-    return false;
 }
 
 // Stepwise traversal of the quantized 4-wide tree: an iteration handles one
@@ -664,38 +687,29 @@ template <bool ANYHIT, class STACK>
 __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneState &s, STACK &st, unsigned min_active,
                                                     unsigned max_steps)
 {
-    const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(sc.wnodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.xtris);
+    const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
     RayRegs &r = s.r;
+    // cur: unit << 2 | triangles of the item being visited; tri / tri_end: units of the leaf's
+    // triangles still to test
     unsigned cur = s.cur, tri = s.tri, tri_end = s.tri_end;
     unsigned steps = s.steps;
 
     while (cur != kDone && (steps < max_steps || tri < tri_end)) {
         steps++;
-        if ((cur & kLeafBit) && tri >= tri_end) {
-            unsigned first, count;
-            if (cur & kBigLeafBit) {
-                const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
-                first = bl.first;
-                count = bl.count;
-            } else {
-                first = (cur >> 3) & (kMaxPackedFirst - 1u);
-                count = (cur & 7u) + 1u;
-            }
-            tri = first;
-            tri_end = first + count;
+        if ((cur & 3u) && tri >= tri_end) { // entering a leaf
+            tri = cur >> 2;
+            tri_end = tri + kUnitsPerItem * (cur & 3u);
         }
         const bool in_leaf = tri < tri_end;
-        const float4 *p = in_leaf ? tris + (size_t)tri * 3 : wn + (size_t)cur * 4;
+        const float4 *p = items + (in_leaf ? tri : cur >> 2);
         float4 a0, a1, a2;
-        uint4 ch;
-        load_item(p, __ballot(!in_leaf), a0, a1, a2, ch);
+        load_item(p, a0, a1, a2);
         bool need_pop = false;
         if (!in_leaf) {
-            need_pop = qwide_step<ANYHIT>(a0, a1, a2, ch, s, st, cur);
+            need_pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray(s), r.near_t, r.far_t, st, cur);
         } else {
             const float t = tri_test(a0, a1, make_float2(a2.x, a2.y), r.o, r.d);
-            tri++;
+            tri += kUnitsPerItem;
             if (t >= r.near_t && t < r.far_t) {
                 if (ANYHIT) {
                     s.hit = 1u;
@@ -723,49 +737,37 @@ template <bool ANYHIT, class STACK>
 __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, STACK &st, unsigned min_active,
                                               unsigned max_steps)
 {
-    const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(sc.wnodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.xtris);
+    const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
     RayRegs &r = s.r;
     unsigned cur = s.cur;
     unsigned steps = s.steps;
 
     while (cur != kDone && steps < max_steps) {
-        while (!(cur & kLeafBit) && steps < max_steps) {
+        while (!(cur & 3u) && steps < max_steps) { // kDone has its low bits set
             steps++;
             const unsigned ucur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
             bool pop;
             if (__ballot(cur != ucur) == 0) { // every lane still in this loop is at node ucur
-                const u32x16 n = scalar_load64(wn + (size_t)ucur * 4);
-                pop = qwide_step<ANYHIT>(f4_of(n, 0), f4_of(n, 4), f4_of(n, 8), make_uint4(n[12], n[13], n[14], n[15]),
-                                         s, st, cur);
+                const u32x16 n = scalar_load64(items + (ucur >> 2));
+                pop = qwide_step<ANYHIT>(f4_of(n, 0), f4_of(n, 4), f4_of(n, 8), slab_ray(s), r.near_t, r.far_t, st, cur);
             } else {
-                const float4 *q = wn + (size_t)cur * 4;
+                const float4 *q = items + (cur >> 2);
                 const float4 a0 = q[0];
                 const float4 a1 = q[1];
                 const float4 a2 = q[2];
-                const uint4 ch = *reinterpret_cast<const uint4 *>(q + 3);
-                pop = qwide_step<ANYHIT>(a0, a1, a2, ch, s, st, cur);
+                pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray(s), r.near_t, r.far_t, st, cur);
             }
             if (pop) cur = st.sp ? st.pop() : kDone;
         }
-        if ((cur & kLeafBit) && cur != kDone) {
+        if (cur != kDone && (cur & 3u)) {
             steps++;
-            unsigned first, count;
-            if (cur & kBigLeafBit) {
-                const BigLeaf bl = sc.big_leaves[cur & 0x3FFFFFFFu];
-                first = bl.first;
-                count = bl.count;
-            } else {
-                first = (cur >> 3) & (kMaxPackedFirst - 1u);
-                count = (cur & 7u) + 1u;
-            }
+            const unsigned first = cur >> 2, count = cur & 3u;
             bool occluded = false;
             const unsigned ucur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
             if (__ballot(cur != ucur) == 0) { // one leaf for the whole wave: triangles through the scalar cache
-                const unsigned ufirst = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
-                const unsigned ucount = (unsigned)__builtin_amdgcn_readfirstlane((int)count);
+                const unsigned ufirst = ucur >> 2, ucount = ucur & 3u;
                 for (unsigned i = 0; i < ucount; i++) {
-                    const u32x16 n = scalar_load64(tris + (size_t)(ufirst + i) * 3); // 48 bytes used
+                    const u32x16 n = scalar_load64(items + ufirst + kUnitsPerItem * i); // 48 bytes used
                     const float t = tri_test(f4_of(n, 0), f4_of(n, 4),
                                              make_float2(__uint_as_float(n[8]), __uint_as_float(n[9])), r.o, r.d);
                     if (!occluded && t >= r.near_t && t < r.far_t) {
@@ -780,10 +782,10 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
                 }
             } else {
                 for (unsigned i = 0; i < count; i++) {
-                    const size_t base = (size_t)(first + i) * 3;
-                    const float4 t0 = tris[base + 0];
-                    const float4 t1 = tris[base + 1];
-                    const float2 t2 = *reinterpret_cast<const float2 *>(tris + base + 2);
+                    const float4 *q = items + first + kUnitsPerItem * i;
+                    const float4 t0 = q[0];
+                    const float4 t1 = q[1];
+                    const float2 t2 = *reinterpret_cast<const float2 *>(q + 2);
                     const float t = tri_test(t0, t1, t2, r.o, r.d);
                     if (t >= r.near_t && t < r.far_t) {
                         if (ANYHIT) {
@@ -807,6 +809,156 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
     s.cur = cur;
     s.steps = steps;
 }
+
+// Cooperative finish of ONE ray of a wide form by the whole wave: the same scheme as coop_finish()
+// below on the wide tree itself.  An entry of the work stack is a traversal reference with the
+// entry distance of its box; a node entry tests its four children and pushes the hit ones,
+// farthest first; a leaf entry tests its triangles.
+struct CoopItem {
+    unsigned ref;
+    float tnear;
+};
+
+template <bool ANYHIT, class STATE, int BLOCK, int LDS_DEPTH>
+__device__ __forceinline__ void coop_finish_wide(const SceneDev &sc, STATE &s, Stack<BLOCK, LDS_DEPTH> &st,
+                                                 unsigned p, CoopItem *work, unsigned cap)
+{
+    const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
+    const unsigned lane = lane_id();
+    // the ray of lane p, in every lane
+    struct {
+        RayRegs r;
+    } ray;
+    ray.r.o = v3(__shfl(s.r.o.x, p), __shfl(s.r.o.y, p), __shfl(s.r.o.z, p));
+    ray.r.d = v3(__shfl(s.r.d.x, p), __shfl(s.r.d.y, p), __shfl(s.r.d.z, p));
+    ray.r.rd = v3(__shfl(s.r.rd.x, p), __shfl(s.r.rd.y, p), __shfl(s.r.rd.z, p));
+    ray.r.near_t = __shfl(s.r.near_t, p);
+    const SlabRay sray = slab_ray(ray.r); // o * (1/d) rounded as lane_begin rounds it
+    float far_t = __shfl(s.r.far_t, p);
+    unsigned hit = (unsigned)__shfl((int)s.hit, p);
+
+    // seed: lane p's stack entries (lane e reads entry e) and its current item
+    const int sp_p = __shfl(st.sp, p);
+    const unsigned cur_p = (unsigned)__shfl((int)s.cur, p);
+    unsigned count = 0; // wave-uniform
+    {
+        unsigned *lds_p = st.lds - (threadIdx.x & 63) + p; // column of lane p
+        unsigned *ovf_p = st.ovf - (size_t)(threadIdx.x & 63) + p;
+        for (int e = (int)lane; e < sp_p; e += 64) {
+            const unsigned ref = e < LDS_DEPTH ? lds_p[e * BLOCK] : ovf_p[(size_t)(e - LDS_DEPTH) * st.ovf_stride];
+            work[e] = CoopItem{ref, -__builtin_inff()};
+        }
+        count = (unsigned)sp_p;
+        if (lane == 0) work[count] = CoopItem{cur_p, -__builtin_inff()};
+        count += 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // Stack bound.  Popping m entries pushes at most 4m, so a batch is sized to keep
+    // count <= lim = cap - reserve; at the limit one entry is popped per iteration, a plain
+    // depth-first walk that grows the stack by at most three entries per level.
+    const unsigned lim = cap - (3u * sc.wmax_depth + 8u);
+    bool found = false; // any-hit result (wave-uniform)
+    while (count != 0 && !(ANYHIT && found)) {
+        unsigned m = count < 64u ? count : 64u;
+        if (count + 3u * m > lim) {
+            m = lim > count ? (lim - count) / 3u : 0u;
+            if (m == 0) m = 1;
+        }
+        CoopItem it{kDone, 0.f};
+        if (lane < m) it = work[count - 1u - lane];
+        count -= m;
+        const bool active = lane < m && it.tnear <= far_t;
+
+        float best_t = __builtin_inff();
+        unsigned best_id = 0xFFFFFFFFu;
+        unsigned key[4] = {kMissKey, kMissKey, kMissKey, kMissKey}; // children to push, nearest in key[0]
+        float kn[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned base4 = 0, meta = 0;
+        if (active && !(it.ref & 3u)) {
+            const float4 *q = items + (it.ref >> 2);
+            const float4 a0 = q[0], a1 = q[1], a2 = q[2];
+            float f[4];
+            qnode_slabs(a0, a1, a2, sray, ray.r.near_t, far_t, kn, f);
+            base4 = __float_as_uint(a1.x);
+            meta = __float_as_uint(a1.y);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (kn[i] <= f[i]) key[i] = (__float_as_uint(kn[i]) & ~3u) | (unsigned)i;
+            RTC_CE(key[0], key[1]);
+            RTC_CE(key[2], key[3]);
+            RTC_CE(key[0], key[2]);
+            RTC_CE(key[1], key[3]);
+            RTC_CE(key[1], key[2]);
+        } else if (active) {
+            const unsigned first = it.ref >> 2, n = it.ref & 3u;
+            float lane_far = far_t;
+            for (unsigned i = 0; i < n; i++) {
+                const float4 *q = items + first + kUnitsPerItem * i;
+                const float4 t0 = q[0];
+                const float4 t1 = q[1];
+                const float2 t2 = *reinterpret_cast<const float2 *>(q + 2);
+                const float t = tri_test(t0, t1, t2, ray.r.o, ray.r.d);
+                if (t >= ray.r.near_t && t < lane_far) {
+                    lane_far = t;
+                    best_t = t;
+                    best_id = __float_as_uint(t2.y);
+                    if (ANYHIT) break;
+                }
+            }
+        }
+
+        // combine the lanes' hits
+        if (ANYHIT) {
+            found = __ballot(best_t < __builtin_inff()) != 0;
+        } else {
+            float wt = best_t;
+            unsigned wi = best_id;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ot = __shfl_xor(wt, off);
+                const unsigned oi = (unsigned)__shfl_xor((int)wi, off);
+                if (ot < wt || (ot == wt && oi < wi)) {
+                    wt = ot;
+                    wi = oi;
+                }
+            }
+            if (wt < far_t) {
+                far_t = wt;
+                hit = wi;
+            }
+        }
+
+        // push the children: every lane's farthest first, its nearest last (on top)
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            const bool push = key[j] != kMissKey;
+            const unsigned long long mask = __ballot(push);
+            if (push) {
+                // the key holds the entry distance rounded down to a multiple of 4 ulp: conservative for
+                // the cull at pop time
+                work[count + prefix_count(mask)] =
+                    CoopItem{child_ref(base4, meta, key[j] & 3u), __uint_as_float(key[j] & ~3u)};
+            }
+            count += (unsigned)__popcll(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (lane == p) {
+        if (ANYHIT) {
+            s.hit = found ? 1u : s.hit;
+        } else {
+            s.hit = hit;
+            s.r.far_t = far_t;
+        }
+        s.cur = kDone;
+        s.tri = s.tri_end = 0;
+        st.sp = 0;
+    }
+}
 #undef RTC_CE
 
 // Cooperative finish of ONE ray by the whole wave.
@@ -826,18 +978,12 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
 // triangle arithmetic on a superset of candidates); on an exact-distance tie
 // the id may be another triangle of the tie, and visit counters of such a ray
 // differ (other visit order, pop-time culling).
-struct CoopItem {
-    unsigned ref;
-    float tnear;
-};
-
-template <bool ANYHIT, bool STATS, bool WIDE, int BLOCK, int LDS_DEPTH>
+template <bool ANYHIT, bool STATS, int BLOCK, int LDS_DEPTH>
 __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, Stack<BLOCK, LDS_DEPTH> &st, Counters &cnt,
                                          unsigned p, CoopItem *work, unsigned cap)
 {
-    // a ray parked by a wide form continues in the refined binary tree the wide tree was made from
-    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(WIDE ? sc.xnodes : sc.nodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(WIDE ? sc.xtris : sc.tris);
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(sc.tris);
     const unsigned lane = lane_id();
 
     // the ray of lane p, in every lane
@@ -865,16 +1011,11 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
                 ref = lds_p[e * BLOCK];
             else
                 ref = ovf_p[(size_t)(e - LDS_DEPTH) * st.ovf_stride];
-            // a ray parked by the 4-wide traversal holds wide node indices: continue in
-            // the binary node each of them was collapsed from
-            if (WIDE && !(ref & kLeafBit)) ref = sc.wbin[ref];
             work[e] = CoopItem{ref, -__builtin_inff()};
         }
         count = (unsigned)sp_p;
         if (lane == 0) {
-            unsigned ref = cur_p;
-            if (WIDE && !(ref & kLeafBit)) ref = sc.wbin[ref];
-            work[count] = CoopItem{ref, -__builtin_inff()};
+            work[count] = CoopItem{cur_p, -__builtin_inff()};
         }
         count += 1;
     }
@@ -885,7 +1026,7 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
     // count <= lim = cap - reserve; at the limit one entry is popped per iteration,
     // which is a plain depth-first walk and grows the stack by at most the tree depth
     // (reserve = max_depth + 2).  The host guarantees cap > reserve + 64 + max_depth.
-    const unsigned lim = cap - ((WIDE ? sc.xmax_depth : sc.max_depth) + 2u);
+    const unsigned lim = cap - (sc.max_depth + 2u);
     bool found = false; // any-hit result (wave-uniform)
     while (count != 0 && !(ANYHIT && found)) {
         unsigned m = count < 64u ? count : 64u;
@@ -1267,7 +1408,10 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
             while (parked != 0) {
                 const unsigned p = (unsigned)__ffsll((long long)parked) - 1u;
-                coop_finish<ANYHIT, STATS, kWide>(sc, s, st, cnt, p, work, tl.coop_cap);
+                if (kWide)
+                    coop_finish_wide<ANYHIT>(sc, s, st, p, work, tl.coop_cap);
+                else
+                    coop_finish<ANYHIT, STATS>(sc, s, st, cnt, p, work, tl.coop_cap);
                 parked &= parked - 1ull;
             }
         }
@@ -1283,6 +1427,214 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
         }
     }
     flush_stats<STATS>(cnt, nrays, tl.stats, tl.depth);
+}
+
+// ------------------------------------------------------------------------
+// Two rays per lane (traversal form 5, incoherent rays on the wide tree).
+//
+// One stepwise iteration ends in a wait for the slowest of the wave's gathers, and with incoherent
+// rays nearly every iteration has a lane that goes to HBM: a wave spends most of its life in
+// s_waitcnt, and the five waves a SIMD holds at this register budget do not cover that.  Here a
+// lane walks two rays, A and B, in turn: the loads of B's next item are issued before A's step is
+// computed and the other way round, so each wave always has one gather in flight behind its
+// arithmetic -- the memory-level parallelism of twice the waves for the registers of one more ray
+// state.  Per ray the walk is traverse_wide_steps(): same items, same order, same results.
+
+struct DualState {
+    RayRegs r;
+    unsigned cur, tri, tri_end; // as in traverse_wide_steps
+    unsigned hit, index, steps;
+    bool have_ray;
+};
+
+constexpr int kDualLdsDepth = RTC_DUAL_LDS_STACK_DEPTH;
+
+template <bool ANYHIT>
+__device__ __forceinline__ bool dual_running(const DualState &x, unsigned max_steps)
+{
+    return x.cur != kDone && (x.steps < max_steps || x.tri < x.tri_end);
+}
+
+// Enters a leaf when the ray has just reached one; returns the item the ray's next step needs.  A
+// lane whose ray is not walking reads the root instead: the gather is issued by every lane, always,
+// so that the number of loads in flight does not depend on the path taken and a wait for one ray's
+// data can leave exactly the other ray's three loads outstanding.
+__device__ __forceinline__ const float4 *dual_item(const float4 *items, DualState &x, bool running)
+{
+    if (running && (x.cur & 3u) && x.tri >= x.tri_end) {
+        x.tri = x.cur >> 2;
+        x.tri_end = x.tri + kUnitsPerItem * (x.cur & 3u);
+    }
+    const unsigned unit = x.tri < x.tri_end ? x.tri : x.cur >> 2;
+    return items + (running ? unit : 0u);
+}
+
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ void dual_step(DualState &x, STACK &st, const float4 a0, const float4 a1, const float4 a2)
+{
+    x.steps++;
+    bool need_pop;
+    if (!(x.tri < x.tri_end)) {
+        need_pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray(x.r), x.r.near_t, x.r.far_t, st, x.cur);
+    } else {
+        const float t = tri_test(a0, a1, make_float2(a2.x, a2.y), x.r.o, x.r.d);
+        x.tri += kUnitsPerItem;
+        if (t >= x.r.near_t && t < x.r.far_t) {
+            if (ANYHIT) {
+                x.hit = 1u;
+                x.cur = kDone;
+                x.tri = x.tri_end;
+            } else {
+                x.r.far_t = t;
+                x.hit = __float_as_uint(a2.y);
+            }
+        }
+        need_pop = (x.tri >= x.tri_end) && (x.cur != kDone);
+    }
+    if (need_pop) x.cur = st.sp ? st.pop_isolated() : kDone;
+}
+
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ void traverse_wide_dual(const SceneDev &sc, DualState &A, DualState &B, STACK &stA, STACK &stB,
+                                                   unsigned min_running, unsigned max_steps)
+{
+    const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
+    float4 a0, a1, a2, b0, b1, b2;
+    bool ra = dual_running<ANYHIT>(A, max_steps);
+    {
+        const float4 *p = dual_item(items, A, ra);
+        a0 = p[0];
+        a1 = p[1];
+        a2 = p[2];
+    }
+    for (;;) {
+        const bool rb = dual_running<ANYHIT>(B, max_steps);
+        { // B's gather goes out before A's arithmetic
+            const float4 *p = dual_item(items, B, rb);
+            b0 = p[0];
+            b1 = p[1];
+            b2 = p[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ra) dual_step<ANYHIT>(A, stA, a0, a1, a2);
+        ra = dual_running<ANYHIT>(A, max_steps);
+        {
+            const float4 *p = dual_item(items, A, ra);
+            a0 = p[0];
+            a1 = p[1];
+            a2 = p[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rb) dual_step<ANYHIT>(B, stB, b0, b1, b2);
+        const unsigned running = (unsigned)__popcll(__ballot(ra)) +
+                                 (unsigned)__popcll(__ballot(dual_running<ANYHIT>(B, max_steps)));
+        if (running < min_running) break; // (the gather of A's issued above is repeated on re-entry)
+    }
+}
+
+template <bool ANYHIT, class IO>
+__global__ __launch_bounds__(kBlock, RTC_DUAL_WAVES_PER_SIMD) void trace_kernel_dual(SceneDev sc, IO io, const unsigned *n_ptr,
+                                                                                  unsigned n_val, TraceLaunch tl)
+{
+    __shared__ unsigned lds_stack[2 * kDualLdsDepth * kBlock];
+    const unsigned n = n_ptr ? *n_ptr : n_val;
+    const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned threads = gridDim.x * kBlock;
+    Stack<kBlock, kDualLdsDepth> st[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { // the two stacks of a lane: separate LDS planes, interleaved overflow columns
+        st[k].lds = lds_stack + k * kDualLdsDepth * kBlock + threadIdx.x;
+        st[k].ovf = tl.ovf + (size_t)k * threads + gtid;
+        st[k].ovf_stride = 2u * threads;
+        st[k].sp = 0;
+    }
+    const unsigned range_len = (n + kFetchRanges - 1u) / kFetchRanges;
+    unsigned range = (gtid >> 6) % kFetchRanges; // wave-uniform
+    unsigned ranges_left = kFetchRanges;         // ranges not yet seen empty by this wave
+    const unsigned lane = lane_id();
+
+    DualState s[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        s[k].cur = kDone;
+        s[k].tri = s[k].tri_end = 0;
+        s[k].steps = 0;
+        s[k].have_ray = false;
+    }
+
+    while (true) {
+        // ---- refill the idle slots, A's then B's (trace_kernel's fetch, once per slot)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            unsigned long long idle_mask = __ballot(!s[k].have_ray);
+            while (ranges_left != 0 && idle_mask != 0) {
+                const unsigned need = (unsigned)__popcll(idle_mask);
+                const unsigned rank = prefix_count(idle_mask);
+                const unsigned leader = (unsigned)__ffsll((long long)idle_mask) - 1u;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&tl.fetch[range * kFetchStride], need);
+                base = (unsigned)__shfl((int)base, (int)leader);
+                const unsigned begin = range * range_len;
+                const unsigned end = (begin + range_len < n) ? begin + range_len : n;
+                const unsigned idx = begin + base + rank;
+                if (!s[k].have_ray && begin + base < end && idx < end) {
+                    unsigned ray = idx;
+                    if (tl.perm && idx < tl.perm_n) {
+                        ray = tl.perm[idx];
+                        if (ray >= n) ray = idx;
+                    }
+                    RayRegs loaded = io.load(ray);
+                    // bounded reciprocal and retirement of non-finite rays: see trace_kernel
+                    const float tiny = 1e-24f;
+                    const float dx = fabsf(loaded.d.x) < tiny ? copysignf(tiny, loaded.d.x) : loaded.d.x;
+                    const float dy = fabsf(loaded.d.y) < tiny ? copysignf(tiny, loaded.d.y) : loaded.d.y;
+                    const float dz = fabsf(loaded.d.z) < tiny ? copysignf(tiny, loaded.d.z) : loaded.d.z;
+                    loaded.rd = v3(1.f / dx, 1.f / dy, 1.f / dz);
+                    s[k].r = loaded;
+                    s[k].cur = sc.wroot_ref;
+                    s[k].tri = s[k].tri_end = 0;
+                    s[k].hit = 0xFFFFFFFFu;
+                    s[k].index = ray;
+                    s[k].steps = 0;
+                    s[k].have_ray = true;
+                    st[k].sp = 0;
+                    const float probe = ((loaded.o.x * 0.f + loaded.o.y * 0.f) + loaded.o.z * 0.f) +
+                                        ((loaded.d.x * 0.f + loaded.d.y * 0.f) + loaded.d.z * 0.f);
+                    if (!(probe == 0.f)) s[k].cur = kDone;
+                }
+                if (begin + base + need > end || begin >= end) {
+                    range = (range + 1u) % kFetchRanges;
+                    ranges_left--;
+                }
+                idle_mask = __ballot(!s[k].have_ray);
+            }
+        }
+        if (__ballot(s[0].have_ray || s[1].have_ray) == 0) break;
+
+        // ---- traverse: until fewer than min_active of the wave's 128 slots are walking
+        traverse_wide_dual<ANYHIT>(sc, s[0], s[1], st[0], st[1], ranges_left ? 2u * tl.min_active : 1u, tl.coop_steps);
+
+        // ---- stragglers and retirement, per slot
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            unsigned long long parked = __ballot(s[k].have_ray && s[k].cur != kDone && s[k].steps >= tl.coop_steps &&
+                                                 s[k].tri >= s[k].tri_end);
+            CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
+            while (parked != 0) {
+                const unsigned p = (unsigned)__ffsll((long long)parked) - 1u;
+                coop_finish_wide<ANYHIT>(sc, s[k], st[k], p, work, tl.coop_cap);
+                parked &= parked - 1ull;
+            }
+            if (s[k].have_ray && s[k].cur == kDone) {
+                LaneState done; // the IO policies read index, hit and far distance
+                done.index = s[k].index;
+                done.hit = s[k].hit;
+                done.r.far_t = s[k].r.far_t;
+                io.template store<ANYHIT>(done);
+                s[k].have_ray = false;
+            }
+        }
+    }
 }
 
 // rays of one launch by depth; also into total_rays when per-visit statistics are off (with them on
@@ -1815,7 +2167,18 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
                          hipStream_t stream)
 {
     const unsigned grid = trace_grid(n_upper, max_blocks);
-    if ((tl.mode == 2 || tl.mode == 3) && !stats && sc.wnodes) {
+    if (tl.mode == 5 && !stats && sc.witems) {
+        // two rays per lane: half the threads for the same rays in flight
+        const unsigned dual_grid = trace_grid((n_upper + 1u) / 2u, max_blocks);
+        if (anyhit)
+            hipLaunchKernelGGL((trace_kernel_dual<true, IO>), dim3(dual_grid), dim3(kBlock), 0, stream, sc, io, n_ptr,
+                               n_val, tl);
+        else
+            hipLaunchKernelGGL((trace_kernel_dual<false, IO>), dim3(dual_grid), dim3(kBlock), 0, stream, sc, io, n_ptr,
+                               n_val, tl);
+        return;
+    }
+    if ((tl.mode == 2 || tl.mode == 3) && !stats && sc.witems) {
         // 4-wide tree, no visit counters in these forms
         if (tl.mode == 2) {
             if (anyhit)
@@ -1870,7 +2233,7 @@ void launch_extend_primary(const SceneDev &sc, const CameraDev &cam, const PassD
     const PrimaryIO io{cam, ps, hit_ids, hit_t};
     const unsigned n = ps.num_slots;
     const unsigned grid = trace_grid(n, max_blocks);
-    const unsigned mode = ((tl.mode >= 2 && !sc.wnodes) || tl.mode > 3) ? 1u : tl.mode;
+    const unsigned mode = ((tl.mode >= 2 && !sc.witems) || tl.mode > 3) ? 1u : tl.mode;
     switch (mode) {
     case 0:
         launch_one<false, false, 0, PrimaryIO>(sc, io, nullptr, n, grid, tl, stream);

@@ -159,7 +159,7 @@ struct rt_scene {
     rt_ctx *ctx = nullptr;
     HostBvh host;
     uint32_t num_triangles = 0;
-    DevBuf nodes, wnodes, wbin, xnodes, xtris, tris, big, normals;
+    DevBuf nodes, witems, tris, big, normals;
     uint32_t num_wide_nodes = 0;
     uint32_t stack_bound = 0; // entries a lane's traversal stack can need on this scene
     SceneDev dev{};
@@ -175,6 +175,9 @@ static int ensure_overflow(rt_ctx *ctx, unsigned max_depth)
     // entries a lane can need beyond the LDS part of its stack, for the kernel with the smallest LDS part
     constexpr unsigned in_lds = (unsigned)(RTC_MIN_LDS_STACK_DEPTH);
     unsigned need = max_depth + 1 > in_lds ? max_depth + 1 - in_lds : 1;
+    // the two-rays-per-lane form keeps two stacks per lane with fewer LDS entries each
+    constexpr unsigned dual_lds = (unsigned)(RTC_DUAL_LDS_STACK_DEPTH);
+    need = std::max(need, 2u * (max_depth + 1 > dual_lds ? max_depth + 1 - dual_lds : 1u));
     if (need <= ctx->ovf_depth) return RT_OK;
     size_t threads = (size_t)ctx->max_blocks * RTC_TRACE_BLOCK;
     int rc = ctx->ovf.ensure(threads * need * sizeof(unsigned));
@@ -191,7 +194,10 @@ static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl)
     tl.coop_cap = ctx->coop_cap;
     // the work stack takes over a lane's whole traversal stack and then needs the
     // headroom coop_finish documents
-    tl.coop_steps = (2u * sc->dev.xmax_depth + 68u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
+    // the binary finisher keeps max_depth + 2 entries in reserve, the wide one 3 * wide depth + 8, on top
+    // of a lane's whole stack and one batch of 64
+    const unsigned reserve = std::max(sc->dev.max_depth + 2u, 3u * sc->dev.wmax_depth + 8u);
+    tl.coop_steps = (reserve + 4u * 64u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
 }
 
 static int timed_begin(rt_ctx *ctx, int kind, hipStream_t s, size_t *slot)
@@ -259,7 +265,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_FUSE_PRIMARY")) ctx->fuse_primary = atoi(env) ? 1u : 0u;
     if (const char *env = getenv("RTCORE_TRAVERSAL_STREAM")) {
         int v = atoi(env);
-        if (v >= 0 && v <= 4) ctx->trav_stream = (unsigned)v;
+        if (v >= 0 && v <= 5) ctx->trav_stream = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
         int v = atoi(env);
@@ -267,7 +273,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP")) {
         int v = atoi(env);
-        if (v >= 0 && v <= 3) ctx->trav_mode[1] = (unsigned)v;
+        if ((v >= 0 && v <= 3) || v == 5) ctx->trav_mode[1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_SORT_EXTEND_FROM")) ctx->sort_from_depth[0] = (unsigned)atoi(env);
     if (const char *env = getenv("RTCORE_SORT_CONNECT_FROM")) ctx->sort_from_depth[1] = (unsigned)atoi(env);
@@ -366,11 +372,11 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->fuse_primary = (unsigned)value;
     } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
         ctx->fast_tree_buckets = (unsigned)value;
-    } else if (n == "traversal_stream" && in(0, 4)) {
+    } else if (n == "traversal_stream" && in(0, 5)) {
         ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
         ctx->trav_mode[0] = (unsigned)value;
-    } else if (n == "traversal_deep" && in(0, 3)) {
+    } else if (n == "traversal_deep" && (in(0, 3) || value == 5)) {
         ctx->trav_mode[1] = (unsigned)value;
     } else if (n == "sort_extend_from" && in(0, 0xFFFFFFFFll)) {
         ctx->sort_from_depth[0] = (unsigned)value;
@@ -629,10 +635,10 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     std::vector<DevTri> dt;
     make_tris(hb.order, dt);
     // the wide tree is built over a copy of the tree whose larger leaves are split further
-    unsigned leaf_tris = 3;
+    unsigned leaf_tris = kWideLeafTris;
     if (const char *env = getenv("RTCORE_WIDE_LEAF_TRIS")) {
         int v = atoi(env);
-        if (v >= 1 && v <= 8) leaf_tris = (unsigned)v;
+        if (v >= 1 && v <= (int)kWideLeafTris) leaf_tris = (unsigned)v;
     }
     std::vector<DevNode> xdn;
     std::vector<uint32_t> xorder;
@@ -649,15 +655,15 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         const BuildTuning tune{search_buckets, leaf_tris};
         build_bvh(positions, num_vertices, indices, num_triangles, threads, hs, &tune);
         std::vector<DevNode> sdn;
-        const uint32_t sroot = make_dev_nodes(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, sdn, big);
-        extra_depth = refine_leaves(sdn, sroot, positions, indices, hs.order, leaf_tris, xdn, xroot, xorder);
+        std::vector<BigLeaf> sbig;
+        const uint32_t sroot = make_dev_nodes(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, sdn, sbig);
+        extra_depth = refine_leaves(sdn, sroot, positions, indices, hs.order, leaf_tris, sbig, xdn, xroot, xorder);
         fast_depth = hs.stats.max_depth;
     } else {
-        extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, xdn, xroot, xorder);
+        extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, big, xdn, xroot, xorder);
     }
     std::vector<DevTri> xdt;
     make_tris(xorder, xdt);
-    xdt.resize(xdt.size() + 1, DevTri{}); // the scalar path reads a triangle as 64 bytes
     std::vector<float> n4((size_t)num_triangles * 4);
     for (uint32_t t = 0; t < num_triangles; t++) {
         n4[4 * (size_t)t + 0] = geom_normals[3 * (size_t)t + 0];
@@ -677,14 +683,17 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     uint32_t wide_depth = 0;
     const uint32_t wroot = collapse_wide4(xdn.data(), xdn.size(), xroot, wn, &wide_depth);
     sc->num_wide_nodes = (uint32_t)wn.size();
-    std::vector<DevQWideNode> qn;
-    std::vector<uint32_t> wbin;
-    quantize_wide4(wn, qn, wbin);
+    WideLayout layout;
+    unsigned align_mode = 0;
+    if (const char *env = getenv("RTCORE_WIDE_ALIGN")) align_mode = (unsigned)atoi(env);
+    if (!layout_wide4(wn, wroot, num_triangles, layout, align_mode))
+        return fail(RT_ERR_LIMIT, "rt_scene_create: the wide tree has a leaf of more than %u triangles", kWideLeafTris);
+    if (layout.num_units >= (1u << 30))
+        return fail(RT_ERR_LIMIT, "rt_scene_create: %u units in the wide tree, limit is 2^30", layout.num_units);
+    std::vector<Unit> items;
+    pack_wide4(wn, layout, xdt.data(), num_triangles, items);
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
-    if (rc == RT_OK) rc = upload(sc->wnodes, qn.data(), qn.size() * sizeof(DevQWideNode));
-    if (rc == RT_OK) rc = upload(sc->wbin, wbin.data(), wbin.size() * sizeof(uint32_t));
-    if (rc == RT_OK) rc = upload(sc->xnodes, xdn.data(), xdn.size() * sizeof(DevNode));
-    if (rc == RT_OK) rc = upload(sc->xtris, xdt.data(), xdt.size() * sizeof(DevTri));
+    if (rc == RT_OK) rc = upload(sc->witems, items.data(), items.size() * sizeof(Unit));
     if (rc == RT_OK) rc = upload(sc->tris, dt.data(), dt.size() * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
     if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
@@ -712,12 +721,9 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     sc->dev.big_leaves = (const BigLeaf *)sc->big.p;
     sc->dev.normals = (const float *)sc->normals.p;
     sc->dev.root_ref = root;
-    sc->dev.wnodes = (const DevQWideNode *)sc->wnodes.p;
-    sc->dev.wbin = (const uint32_t *)sc->wbin.p;
-    sc->dev.xnodes = (const DevNode *)sc->xnodes.p;
-    sc->dev.xtris = (const DevTri *)sc->xtris.p;
-    sc->dev.xmax_depth = fast_depth + extra_depth;
-    sc->dev.wroot_ref = wroot;
+    sc->dev.witems = (const Unit *)sc->witems.p;
+    sc->dev.wroot_ref = layout.root_ref;
+    sc->dev.wmax_depth = wide_depth;
     sc->dev.max_depth = hb.stats.max_depth;
     return RT_OK;
 }
@@ -779,8 +785,9 @@ extern "C" int rt_bvh_build_search_host(const float *positions, uint32_t num_ver
 }
 
 extern "C" int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, uint32_t root_ref,
-                                uint32_t root_count, rt_wide_node *out, rt_qwide_node *qout, uint32_t *num_wide,
-                                uint32_t *wide_root_ref, uint32_t *wide_depth)
+                                uint32_t root_count, uint32_t num_triangles, rt_wide_node *out, rt_qwide_node *qout,
+                                uint32_t *node_unit, uint32_t *slot_unit, uint32_t *num_wide, uint32_t *wide_root_ref,
+                                uint32_t *wide_depth, uint32_t *num_units)
 {
     if ((num_nodes && !nodes) || !num_wide || !wide_root_ref)
         return fail(RT_ERR_INVALID, "rt_bvh_wide_host: NULL argument");
@@ -803,12 +810,21 @@ extern "C" int rt_bvh_wide_host(const rt_flat_node *nodes, uint32_t num_nodes, u
         if (wide_depth) *wide_depth = depth;
         static_assert(sizeof(rt_wide_node) == sizeof(DevWideNode), "rt_wide_node is the device layout");
         if (out && !wn.empty()) memcpy(out, wn.data(), wn.size() * sizeof(DevWideNode));
-        if (qout && !wn.empty()) {
-            std::vector<DevQWideNode> qn;
-            std::vector<uint32_t> wbin;
-            quantize_wide4(wn, qn, wbin);
-            static_assert(sizeof(rt_qwide_node) == sizeof(DevQWideNode), "rt_qwide_node is the device layout");
-            memcpy(qout, qn.data(), qn.size() * sizeof(DevQWideNode));
+        if (qout || node_unit || slot_unit || num_units) {
+            WideLayout layout;
+            if (!layout_wide4(wn, *wide_root_ref, num_triangles, layout))
+                return fail(RT_ERR_INVALID,
+                            "rt_bvh_wide_host: the device form needs leaves of at most %u triangles inside [0, %u) "
+                            "(refine the tree first)", kWideLeafTris, num_triangles);
+            static_assert(sizeof(rt_qwide_node) == sizeof(DevQNode), "rt_qwide_node is the device layout");
+            if (qout)
+                for (size_t w = 0; w < wn.size(); w++) {
+                    const DevQNode q = quantize_node(wn[w], layout);
+                    memcpy(&qout[w], &q, sizeof q);
+                }
+            if (node_unit && !wn.empty()) memcpy(node_unit, layout.node_unit.data(), wn.size() * sizeof(uint32_t));
+            if (slot_unit && num_triangles) memcpy(slot_unit, layout.slot_unit.data(), (size_t)num_triangles * sizeof(uint32_t));
+            if (num_units) *num_units = layout.num_units;
         }
     } catch (const std::exception &ex) {
         return fail(RT_ERR_NOMEM, "rt_bvh_wide_host: %s", ex.what());
@@ -838,7 +854,7 @@ extern "C" int rt_bvh_refine_host(const float *positions, uint32_t num_vertices,
         const uint32_t root = make_dev_nodes(nodes, num_nodes, root_ref, root_count, dn, big);
         std::vector<uint32_t> ord(order, order + num_triangles), xord;
         uint32_t xroot = root;
-        const uint32_t extra = refine_leaves(dn, root, positions, indices, ord, max_tris, xdn, xroot, xord);
+        const uint32_t extra = refine_leaves(dn, root, positions, indices, ord, max_tris, big, xdn, xroot, xord);
         // back to the canonical encoding: leaf = bit 31 | first slot, with a separate count
         auto unpack = [&](uint32_t ref, uint32_t &out_ref, uint32_t &out_count) {
             if (!(ref & kLeafBit)) {
@@ -877,10 +893,7 @@ extern "C" void rt_scene_destroy(rt_scene *sc)
     (void)hipSetDevice(sc->ctx->device);
     (void)hipDeviceSynchronize();
     sc->nodes.release();
-    sc->wnodes.release();
-    sc->wbin.release();
-    sc->xnodes.release();
-    sc->xtris.release();
+    sc->witems.release();
     sc->tris.release();
     sc->big.release();
     sc->normals.release();

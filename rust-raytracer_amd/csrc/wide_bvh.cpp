@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <thread>
 #include <vector>
@@ -154,6 +155,7 @@ struct Refiner {
     unsigned max_tris;
     std::vector<DevNode> *xn;
     std::vector<uint32_t> *xorder;
+    const std::vector<BigLeaf> *big;
     uint32_t deepest = 0;
 
     Box3 tri_box(uint32_t t) const
@@ -178,10 +180,45 @@ struct Refiner {
     }
     static uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | (first << 3) | (count - 1u); }
 
-    // slots [first, first + n) of xorder, n <= 8; returns the reference that replaces the leaf
+    // a node over slots [first, first + k) and [first + k, first + n) with the exact bounds of both
+    uint32_t emit(uint32_t first, uint32_t k, uint32_t n, const Box3 &box_a, const Box3 &box_b, uint32_t depth)
+    {
+        const uint32_t self = (uint32_t)xn->size();
+        xn->emplace_back();
+        deepest = std::max(deepest, depth);
+        const uint32_t l = split(first, k, depth + 1);
+        const uint32_t r = split(first + k, n - k, depth + 1);
+        DevNode &d = (*xn)[self];
+        float *b[3] = {d.bx, d.by, d.bz};
+        for (int a = 0; a < 3; a++) {
+            b[a][0] = box_a.lo[a];
+            b[a][1] = box_b.lo[a];
+            b[a][2] = box_a.hi[a];
+            b[a][3] = box_b.hi[a];
+        }
+        d.left = l;
+        d.right = r;
+        d.pad0 = d.pad1 = 0;
+        return self;
+    }
+    // nothing to order the triangles by (or too many for the exhaustive cut): halves by slot
+    uint32_t halve(uint32_t first, uint32_t n, uint32_t depth)
+    {
+        const uint32_t *slot = xorder->data() + first;
+        const uint32_t k = n / 2;
+        Box3 a, b;
+        a.reset();
+        b.reset();
+        for (uint32_t i = 0; i < k; i++) a.grow(tri_box(slot[i]));
+        for (uint32_t i = k; i < n; i++) b.grow(tri_box(slot[i]));
+        return emit(first, k, n, a, b, depth);
+    }
+
+    // slots [first, first + n) of xorder; returns the reference that replaces the leaf
     uint32_t split(uint32_t first, uint32_t n, uint32_t depth)
     {
         if (n <= max_tris) return leaf_ref(first, n);
+        if (n > 8) return halve(first, n, depth);
         uint32_t *slot = xorder->data() + first;
         float clo[3], chi[3];
         for (int k = 0; k < 3; k++) {
@@ -197,7 +234,7 @@ struct Refiner {
         int axis = 0;
         for (int k = 1; k < 3; k++)
             if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-        if (!(chi[axis] - clo[axis] > 0.f)) return leaf_ref(first, n); // nothing to order by
+        if (!(chi[axis] - clo[axis] > 0.f)) return halve(first, n, depth);
         std::stable_sort(slot, slot + n, [&](uint32_t a, uint32_t b) {
             const float ca = centroid(a, axis), cb = centroid(b, axis);
             return ca < cb || (ca == cb && a < b);
@@ -222,28 +259,15 @@ struct Refiner {
                 best_a = prefix;
             }
         }
-        const Box3 box_a = best_a, box_b = suffix[best_k];
-        const uint32_t self = (uint32_t)xn->size();
-        xn->emplace_back();
-        deepest = std::max(deepest, depth);
-        const uint32_t l = split(first, best_k, depth + 1);
-        const uint32_t r = split(first + best_k, n - best_k, depth + 1);
-        DevNode &d = (*xn)[self];
-        float *b[3] = {d.bx, d.by, d.bz};
-        for (int k = 0; k < 3; k++) {
-            b[k][0] = box_a.lo[k];
-            b[k][1] = box_b.lo[k];
-            b[k][2] = box_a.hi[k];
-            b[k][3] = box_b.hi[k];
-        }
-        d.left = l;
-        d.right = r;
-        d.pad0 = d.pad1 = 0;
-        return self;
+        return emit(first, best_k, n, best_a, suffix[best_k], depth);
     }
     uint32_t refine_ref(uint32_t ref)
     {
-        if (!(ref & kLeafBit) || (ref & kBigLeafBit)) return ref;
+        if (!(ref & kLeafBit)) return ref;
+        if (ref & kBigLeafBit) {
+            const BigLeaf &bl = (*big)[ref & 0x3FFFFFFFu];
+            return split(bl.first, bl.count, 1);
+        }
         const uint32_t first = (ref >> 3) & (kMaxPackedFirst - 1u), count = (ref & 7u) + 1u;
         return split(first, count, 1);
     }
@@ -253,7 +277,8 @@ struct Refiner {
 
 uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const float *positions,
                        const uint32_t *indices, const std::vector<uint32_t> &order, unsigned max_tris,
-                       std::vector<DevNode> &xn, uint32_t &xroot, std::vector<uint32_t> &xorder)
+                       const std::vector<BigLeaf> &big, std::vector<DevNode> &xn, uint32_t &xroot,
+                       std::vector<uint32_t> &xorder)
 {
     xn = bn;
     xorder = order;
@@ -269,7 +294,7 @@ uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const 
     std::vector<uint32_t> deepest(T, 0);
     const uint32_t kLocal = 0x40000000u; // marks a reference to a thread-local new node (inner refs stay below)
     run_parallel(T, [&](unsigned t) {
-        Refiner rf{positions, indices, max_tris, &made[t], &xorder};
+        Refiner rf{positions, indices, max_tris, &made[t], &xorder, &big};
         const size_t lo = n * t / T, hi = n * (t + 1) / T;
         for (size_t i = lo; i < hi; i++) {
             uint32_t l = rf.refine_ref(bn[i].left);
@@ -303,7 +328,7 @@ uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const 
     // the root is a leaf only in a tree without inner nodes
     {
         std::vector<DevNode> extra;
-        Refiner rf{positions, indices, max_tris, &extra, &xorder};
+        Refiner rf{positions, indices, max_tris, &extra, &xorder, &big};
         const uint32_t r = rf.refine_ref(root_ref);
         if (r != root_ref && !(r & kLeafBit)) {
             const uint32_t b = (uint32_t)xn.size();
@@ -321,60 +346,154 @@ uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const 
     return deep;
 }
 
-void quantize_wide4(const std::vector<DevWideNode> &wide, std::vector<DevQWideNode> &out,
-                    std::vector<uint32_t> &bin)
+bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
+                  unsigned align_mode)
 {
-    out.resize(wide.size());
-    bin.resize(wide.size());
-    const size_t total = wide.size();
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(worker_threads(), total / 4096 + 1));
-    run_parallel(T, [&](unsigned t) {
-    for (size_t w = total * t / T; w < total * (t + 1) / T; w++) {
-        const DevWideNode &src = wide[w];
-        DevQWideNode &q = out[w];
-        bin[w] = src.bin;
-        int n = 0;
-        while (n < 4 && std::isfinite(src.lo[0][n])) n++;
-        for (int k = 0; k < 3; k++) {
-            double nlo = src.lo[k][0], nhi = src.hi[k][0];
-            for (int i = 1; i < n; i++) {
-                nlo = std::min<double>(nlo, src.lo[k][i]);
-                nhi = std::max<double>(nhi, src.hi[k][i]);
-            }
-            const double ext = nhi - nlo;
-            double margin = std::ldexp(std::max({std::fabs(nlo), std::fabs(nhi), ext}), -18);
-            if (!(margin > 0.0)) margin = std::ldexp(1.0, -100); // a node at the coordinate origin with no extent
-            // origin: a float at or below nlo - margin
-            float origin = (float)(nlo - margin);
-            if ((double)origin > nlo - margin) origin = std::nextafterf(origin, -std::numeric_limits<float>::infinity());
-            // scale: a float with origin + 255 * scale >= nhi + margin
-            float scale = (float)((nhi + margin - (double)origin) / 255.0);
-            while ((double)origin + 255.0 * (double)scale < nhi + margin || !(scale > 0.f))
-                scale = std::nextafterf(scale, std::numeric_limits<float>::infinity());
-            q.origin[k] = origin;
-            q.scale[k] = scale;
-            uint32_t lo_word = 0, hi_word = 0;
-            for (int i = 0; i < 4; i++) {
-                uint32_t bl = 255, bh = 0; // unused slot: near plane beyond far plane on every axis
-                if (i < n) {
-                    const double lo = (double)src.lo[k][i] - margin, hi = (double)src.hi[k][i] + margin;
-                    double fl = std::floor((lo - (double)origin) / (double)scale);
-                    fl = std::min(255.0, std::max(0.0, fl));
-                    while (fl > 0.0 && (double)origin + fl * (double)scale > lo + 0.5 * margin) fl -= 1.0;
-                    double ch = std::ceil((hi - (double)origin) / (double)scale);
-                    ch = std::min(255.0, std::max(0.0, ch));
-                    while (ch < 255.0 && (double)origin + ch * (double)scale < hi - 0.5 * margin) ch += 1.0;
-                    bl = (uint32_t)fl;
-                    bh = (uint32_t)ch;
-                }
-                lo_word |= bl << (8 * i);
-                hi_word |= bh << (8 * i);
-            }
-            q.lo[k] = lo_word;
-            q.hi[k] = hi_word;
-        }
-        for (int i = 0; i < 4; i++) q.child[i] = src.child[i];
+    // align_mode 0: items back to back; 1: nodes start on 64-byte lines; 2: every item does
+    auto place = [&](uint32_t &next, bool node) {
+        if (align_mode == 2 || (align_mode == 1 && node)) next = (next + 3u) & ~3u;
+    };
+    out.node_unit.assign(wide.size(), 0xFFFFFFFFu);
+    out.slot_unit.assign(num_triangles, 0xFFFFFFFFu);
+    out.num_units = 0;
+    auto leaf_range = [](uint32_t ref, uint32_t &first, uint32_t &count) {
+        first = (ref >> 3) & (kMaxPackedFirst - 1u);
+        count = (ref & 7u) + 1u;
+        return !(ref & kBigLeafBit) && count <= kWideLeafTris;
+    };
+    uint32_t next = 0;
+    if (wroot & kLeafBit) { // a mesh of at most kWideLeafTris triangles: the root is its leaf
+        uint32_t first, count;
+        if (!leaf_range(wroot, first, count) || first + count > num_triangles) return false;
+        for (uint32_t t = 0; t < count; t++) out.slot_unit[first + t] = kUnitsPerItem * t;
+        out.num_units = kUnitsPerItem * count;
+        out.root_ref = count;
+        return true;
     }
+    if (wroot >= wide.size()) return false;
+    out.node_unit[wroot] = 0;
+    next = kUnitsPerItem;
+    out.root_ref = 0;
+    std::vector<uint32_t> todo{wroot};
+    while (!todo.empty()) {
+        const uint32_t w = todo.back();
+        todo.pop_back();
+        const DevWideNode &n = wide[w];
+        int used = 0;
+        while (used < 4 && std::isfinite(n.lo[0][used])) used++;
+        uint32_t inner[4];
+        int ninner = 0;
+        for (int i = 0; i < used; i++) {
+            const uint32_t ref = n.child[i];
+            if (ref & kLeafBit) {
+                uint32_t first, count;
+                if (!leaf_range(ref, first, count) || first + count > num_triangles) return false;
+                if (align_mode == 2) {
+                    return false; // leaves must stay contiguous: not supported with per-item alignment
+                }
+                for (uint32_t t = 0; t < count; t++) out.slot_unit[first + t] = next + kUnitsPerItem * t;
+                next += kUnitsPerItem * count;
+            } else {
+                if (ref >= wide.size() || out.node_unit[ref] != 0xFFFFFFFFu) return false;
+                place(next, true);
+                out.node_unit[ref] = next;
+                next += kUnitsPerItem;
+                inner[ninner++] = ref;
+            }
+        }
+        for (int i = ninner - 1; i >= 0; i--) todo.push_back(inner[i]); // first child's block comes next
+    }
+    out.num_units = next;
+    return true;
+}
+
+DevQNode quantize_node(const DevWideNode &src, const WideLayout &layout)
+{
+    DevQNode q{};
+    int n = 0;
+    while (n < 4 && std::isfinite(src.lo[0][n])) n++;
+    uint32_t exps = 0;
+    for (int k = 0; k < 3; k++) {
+        double nlo = src.lo[k][0], nhi = src.hi[k][0];
+        for (int i = 1; i < n; i++) {
+            nlo = std::min<double>(nlo, src.lo[k][i]);
+            nhi = std::max<double>(nhi, src.hi[k][i]);
+        }
+        const double ext = nhi - nlo;
+        double margin = std::ldexp(std::max({std::fabs(nlo), std::fabs(nhi), ext}), -18);
+        if (!(margin > 0.0)) margin = std::ldexp(1.0, -100); // a node at the coordinate origin with no extent
+        // origin: a float at or below nlo - margin
+        float origin = (float)(nlo - margin);
+        if ((double)origin > nlo - margin) origin = std::nextafterf(origin, -std::numeric_limits<float>::infinity());
+        // step: the smallest float with a 2-bit mantissa (2^e * {1, 1.25, 1.5, 1.75}, ten bits in the
+        // node) with origin + 255 * step >= nhi + margin
+        const double want = (nhi + margin - (double)origin) / 255.0;
+        int e = 0;
+        (void)std::frexp(want, &e); // want = m * 2^e, m in [0.5, 1)
+        e = std::min(127, std::max(-126, e - 1));
+        uint32_t code = (uint32_t)(e + 127) << 2; // exponent << 2 | mantissa
+        auto step_of = [](uint32_t c) { return std::ldexp(1.0 + 0.25 * (double)(c & 3u), (int)(c >> 2) - 127); };
+        while (code < ((254u << 2) | 3u) && (double)origin + 255.0 * step_of(code) < nhi + margin) code++;
+        const double step = step_of(code);
+        q.origin[k] = origin;
+        exps |= code << (10 * k);
+        uint32_t lo_word = 0, hi_word = 0;
+        for (int i = 0; i < 4; i++) {
+            uint32_t bl = 255, bh = 0; // unused slot: near plane beyond far plane on every axis
+            if (i < n) {
+                const double lo = (double)src.lo[k][i] - margin, hi = (double)src.hi[k][i] + margin;
+                double fl = std::floor((lo - (double)origin) / step);
+                fl = std::min(255.0, std::max(0.0, fl));
+                while (fl > 0.0 && (double)origin + fl * step > lo + 0.5 * margin) fl -= 1.0;
+                double ch = std::ceil((hi - (double)origin) / step);
+                ch = std::min(255.0, std::max(0.0, ch));
+                while (ch < 255.0 && (double)origin + ch * step < hi - 0.5 * margin) ch += 1.0;
+                bl = (uint32_t)fl;
+                bh = (uint32_t)ch;
+            }
+            lo_word |= bl << (8 * i);
+            hi_word |= bh << (8 * i);
+        }
+        q.lo[k] = lo_word;
+        q.hi[k] = hi_word;
+    }
+    q.exps = exps;
+    // children block: in slot order, the way layout_wide4 numbered it
+    uint32_t base = 0xFFFFFFFFu, meta = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t ref = src.child[i];
+        uint32_t unit, tris;
+        if (ref & kLeafBit) {
+            unit = layout.slot_unit[(ref >> 3) & (kMaxPackedFirst - 1u)];
+            tris = (ref & 7u) + 1u;
+        } else {
+            unit = layout.node_unit[ref];
+            tris = 0;
+        }
+        if (i == 0) base = unit;
+        meta |= (((unit - base) << 2) | tris) << (8 * i);
+    }
+    for (int i = n; i < 4; i++) meta |= (meta & 0xFFu) << (8 * i);
+    q.base4 = base << 2;
+    q.meta = meta;
+    return q;
+}
+
+void pack_wide4(const std::vector<DevWideNode> &wide, const WideLayout &layout, const DevTri *xtris,
+                uint32_t num_triangles, std::vector<Unit> &items)
+{
+    static_assert(sizeof(DevQNode) == kUnitsPerItem * sizeof(Unit) && sizeof(DevTri) == kUnitsPerItem * sizeof(Unit),
+                  "items are three units");
+    items.assign((size_t)layout.num_units + 1, Unit{});
+    const size_t nodes = wide.size();
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(worker_threads(), (nodes + num_triangles) / 65536 + 1));
+    run_parallel(T, [&](unsigned t) {
+        for (size_t w = nodes * t / T; w < nodes * (t + 1) / T; w++) {
+            const DevQNode q = quantize_node(wide[w], layout);
+            std::memcpy(&items[layout.node_unit[w]], &q, sizeof q);
+        }
+        for (size_t s = (size_t)num_triangles * t / T; s < (size_t)num_triangles * (t + 1) / T; s++)
+            std::memcpy(&items[layout.slot_unit[s]], &xtris[s], sizeof(DevTri));
     });
 }
 

@@ -12,6 +12,9 @@ while args and args[0].startswith("--"):
     elif k == "--spp": spp = v
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for setting in args:
+    if setting.startswith("wl="):
+        wl = setting[3:]
+        continue
     env = dict(os.environ)
     if setting != "base":
         for kv in setting.split(","):

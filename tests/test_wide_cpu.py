@@ -32,30 +32,56 @@ def binary_leaves(nodes, root):
     return out
 
 
-def check_quantized(wide, qwide):
-    """Every decoded box (in double precision) contains the exact child box, is not looser than
-    two grid steps plus the builder's margin per side, and unused slots decode to near > far on every axis."""
-    assert len(wide) == len(qwide)
+def check_quantized(wide, qwide, node_unit, slot_unit, num_units):
+    """The device form of the wide tree.  Every decoded box (in double precision) contains the exact
+    child box, is not looser than two grid steps plus the builder's margin per side, and unused slots
+    decode to near > far on every axis; grid steps carry two mantissa bits; the children block of every
+    node holds its children back to back in slot order, and nodes and triangles tile the unit array
+    (three units each) without gaps or overlaps."""
+    assert len(wide) == len(qwide) == len(node_unit)
+    items = sorted(node_unit.tolist() + slot_unit.tolist())
+    assert items == list(range(0, num_units, 3)), "nodes and triangles must tile the unit array"
+    assert node_unit[0] == 0
     for w, q in zip(wide, qwide):
-        assert np.array_equal(w["child"], q["child"])
         origin = q["origin"].astype(np.float64)
-        scale = q["scale"].astype(np.float64)
-        assert (scale > 0).all()
+        code = np.array([(int(q["exps"]) >> (10 * k)) & 0x3FF for k in range(3)])
+        e = code >> 2
+        assert ((e >= 1) & (e <= 254)).all() and int(q["exps"]) >> 30 == 0
+        scale = np.ldexp(1.0 + 0.25 * (code & 3), e - 127)
+        as_f32 = (code.astype(np.uint32) << 21).view(np.float32)          # how the kernel decodes it
+        assert np.array_equal(as_f32.astype(np.float64), scale)
         used = [i for i in range(4) if np.isfinite(w["lo"][0][i])]
         nlo = w["lo"][:, used].astype(np.float64).min(axis=1)
         nhi = w["hi"][:, used].astype(np.float64).max(axis=1)
         big = np.maximum(np.maximum(np.abs(nlo), np.abs(nhi)), nhi - nlo)
+        # the smallest representable step that reaches the far side: four fifths of it must not
+        assert ((origin + 255 * scale * 0.8 < nhi + np.ldexp(big, -17)) | (code == 4)).all()
+        base, meta = int(q["base4"]) >> 2, int(q["meta"])
+        assert int(q["base4"]) & 3 == 0
+        expect = base
         for i in range(4):
             lo_b = np.array([(int(q["lo"][k]) >> (8 * i)) & 0xFF for k in range(3)], dtype=np.float64)
             hi_b = np.array([(int(q["hi"][k]) >> (8 * i)) & 0xFF for k in range(3)], dtype=np.float64)
+            byte = (meta >> (8 * i)) & 0xFF
             if not np.isfinite(w["lo"][0][i]):
-                assert (lo_b == 255).all() and (hi_b == 0).all()
+                assert (lo_b == 255).all() and (hi_b == 0).all() and byte == meta & 0xFF
                 continue
             dlo, dhi = origin + lo_b * scale, origin + hi_b * scale
             elo, ehi = w["lo"][:, i].astype(np.float64), w["hi"][:, i].astype(np.float64)
             assert (dlo < elo).all() and (dhi > ehi).all()           # strictly outside: the margin
             slack = 2.0 * scale + np.ldexp(big, -17)               # two grid steps plus twice the margin
             assert (elo - dlo <= slack).all() and (dhi - ehi <= slack).all()
+            ref = int(w["child"][i])
+            unit, tris = base + (byte >> 2), byte & 3
+            assert unit == expect                                      # back to back, in slot order
+            if ref & LEAF:
+                first, count = (ref >> 3) & ((1 << 27) - 1), (ref & 7) + 1
+                assert tris == count <= 3
+                assert slot_unit[first:first + count].tolist() == [unit + 3 * t for t in range(count)]
+                expect += 3 * count
+            else:
+                assert tris == 0 and node_unit[ref] == unit
+                expect += 3
 
 
 @pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 3000, "seed": 4}),
@@ -63,7 +89,11 @@ def check_quantized(wide, qwide):
 def test_wide_collapse_invariants(rt, scenes, name, kw):
     sc = scenes.load(name, **kw)
     nodes, order, info, stats = rt.build_bvh_host(sc.positions, sc.indices)
-    wide, qwide, wroot, wdepth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
+    wide, wroot, wdepth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
+    # the device form needs leaves of at most 3 triangles: the reference's tree as it is must be refused
+    if stats["max_objs"] > 3:
+        with pytest.raises(rt.RtError):
+            rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"], len(sc.indices))
     if info["root_ref"] & LEAF:
         assert len(wide) == 0 and wroot == pack(info["root_ref"], info["root_count"])
         return
@@ -111,10 +141,52 @@ def test_wide_collapse_invariants(rt, scenes, name, kw):
             assert all(int(node["child"][i]) & LEAF for i in used)
 
     walk(0)
-    check_quantized(wide, qwide)
     assert int(wide[0]["bin"]) == info["root_ref"]
     assert len(seen_inner) == len(wide) - 1
     assert sorted(leaves) == sorted(binary_leaves(nodes, info["root_ref"])) and len(set(leaves)) == len(leaves)
+
+
+@pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 3000, "seed": 4}),
+                                     ("test-mesh", {"n_tris": 9, "seed": 1}), ("test-mesh", {"n_tris": 5, "seed": 2}),
+                                     ("coincident", {})])
+@pytest.mark.parametrize("builder", ["refined", "search"])
+def test_wide_device_form(rt, scenes, name, kw, builder):
+    """The 48-byte nodes and the unit layout rt_scene_create uploads, from both trees the fast forms
+    can be built over: the reference's tree with its leaves refined to 3 triangles, and the search
+    builder's.  'coincident' adds 20 copies of one triangle (one centroid: a leaf of 20 in either
+    builder), which the refinement must cut down by slot."""
+    if name == "coincident":
+        sc = scenes.load("test-mesh", n_tris=300, seed=6)
+        base = len(sc.positions)
+        positions = np.vstack([sc.positions, [[0.1, 0.1, 5.0], [0.4, 0.1, 5.0], [0.1, 0.4, 5.0]]]).astype(np.float32)
+        indices = np.vstack([sc.indices, np.tile(np.array([[base, base + 1, base + 2]], np.uint32), (20, 1))]).astype(np.uint32)
+    else:
+        sc = scenes.load(name, **kw)
+        positions, indices = sc.positions, sc.indices
+    nt = len(indices)
+    if builder == "refined":
+        nodes, order, info, stats = rt.build_bvh_host(positions, indices)
+    else:
+        nodes, order, info, stats = rt.build_bvh_search_host(positions, indices, 32, 3)
+    xn, xorder, xroot, xcount, extra = rt.refine_bvh_host(positions, indices, nodes, info["root_ref"], info["root_count"],
+                                                          order, 3)
+    assert sorted(xorder.tolist()) == list(range(nt))
+    wide, qwide, node_unit, slot_unit, num_units, wroot, wdepth = rt.wide_bvh_host(xn, xroot, xcount, nt)
+    if xroot & LEAF:
+        assert len(wide) == 0 and num_units == 3 * nt and slot_unit.tolist() == list(range(0, 3 * nt, 3))
+        return
+    assert num_units == 3 * (len(wide) + nt)
+    check_quantized(wide, qwide, node_unit, slot_unit, num_units)
+    # every leaf of the wide tree holds at most 3 triangles and every triangle is in exactly one
+    seen = np.zeros(nt, dtype=np.int64)
+    for w in wide:
+        for i in range(4):
+            ref = int(w["child"][i])
+            if np.isfinite(w["lo"][0][i]) and ref & LEAF:
+                assert not ref & 0x40000000
+                first, count = (ref >> 3) & ((1 << 27) - 1), (ref & 7) + 1
+                seen[xorder[first:first + count]] += 1
+    assert (seen == 1).all()
 
 
 def test_wide_host_rejects_bad_tree(rt):
@@ -124,14 +196,17 @@ def test_wide_host_rejects_bad_tree(rt):
     nodes[0]["right_count"] = 1
     with pytest.raises(rt.RtError):
         rt.wide_bvh_host(nodes, 0, 0)
+    with pytest.raises(rt.RtError):
+        rt.wide_bvh_host(nodes, 0, 0, 1)
 
 
 @pytest.mark.parametrize("max_tris", [1, 2, 3, 4])
 @pytest.mark.parametrize("name,kw", [("cornell-class", {}), ("test-mesh", {"n_tris": 3000, "seed": 4})])
 def test_refined_leaves(rt, scenes, name, kw, max_tris):
     """rt_bvh_refine_host: original nodes keep index and boxes, every reference leaf keeps its slot
-    range and its set of triangles, new leaves hold at most max_tris triangles (unless their
-    centroids coincide), and every new child box is exactly the bound of the triangles below it."""
+    range and its set of triangles, new leaves hold at most max_tris triangles (triangles whose
+    centroids coincide are cut by slot), and every new child box is exactly the bound of the
+    triangles below it."""
     sc = scenes.load(name, **kw)
     nodes, order, info, stats = rt.build_bvh_host(sc.positions, sc.indices)
     xn, xorder, xroot, xcount, extra = rt.refine_bvh_host(sc.positions, sc.indices, nodes, info["root_ref"],
@@ -151,9 +226,7 @@ def test_refined_leaves(rt, scenes, name, kw, max_tris):
         if ref & LEAF:
             first = ref & 0x7FFFFFFF
             lo, hi = bound(first, count)
-            if count > max_tris:   # only leaves whose centroids give nothing to order by stay larger
-                c = P[I[xorder[first:first + count]]].mean(axis=1)
-                assert count > 8 or np.ptp(c, axis=0).max() < 1e-6
+            assert count <= max_tris
             return first, count, lo, hi
         assert ref >= len(nodes)   # new nodes are appended
         n = xn[ref]
@@ -259,7 +332,7 @@ def test_search_builder_invariants(rt, scenes, name, kw, buckets, max_leaf):
             stack.append((int(n["left"]), int(n["left_count"])))
             stack.append((int(n["right"]), int(n["right_count"])))
     if max(sizes) <= 8:
-        wide, qwide, wroot, depth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
+        wide, wroot, depth = rt.wide_bvh_host(nodes, info["root_ref"], info["root_count"])
         assert len(wide) >= 1 or nt <= 8
 
 
