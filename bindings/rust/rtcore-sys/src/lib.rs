@@ -17,6 +17,9 @@ pub const RT_SHARD_SAMPLE: c_int = 0;
 pub const RT_SHARD_TILE: c_int = 1;
 pub const RT_LDS_STACK_ENTRIES: u32 = 24;
 pub const RT_STAT_DEPTHS: usize = 8;
+pub const RT_NOALLOC_MAX_RAYS: u32 = 268_435_456;
+pub const RT_NOALLOC_MAX_STACK: u32 = 56;
+pub const RT_NOALLOC_SCRATCH_BYTES: u32 = 17_825_792;
 
 #[repr(C)]
 pub struct rt_ctx {
@@ -255,6 +258,13 @@ extern "C" {
         d_hits: *mut u32,
         n: u32,
         stats: *mut rt_trace_stats,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn rt_intersect_stream_noalloc(
+        scene: *mut rt_scene,
+        d_rays: *mut rt_stream_ray,
+        d_hits: *mut u32,
+        n: u32,
         hip_stream: *mut c_void,
     ) -> c_int;
     pub fn rt_occluded_stream(

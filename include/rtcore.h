@@ -311,6 +311,26 @@ int rt_intersect_stream(rt_scene *scene, rt_stream_ray *rays, uint32_t *hits, ui
 int rt_intersect_stream_device(rt_scene *scene, rt_stream_ray *d_rays, uint32_t *d_hits,
                                uint32_t n, rt_trace_stats *stats, void *hip_stream);
 
+/* rt_intersect_stream_device for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (which
+ * has no device).  Same inputs, same outputs and the same traversal form (option
+ * "traversal_stream") as rt_intersect_stream_device without statistics, but everything the
+ * kernels need beyond d_rays and d_hits -- the ray-fetch counters and the part of the per-lane
+ * traversal stacks that does not fit in LDS -- lives in one fixed device array of
+ * RT_NOALLOC_SCRATCH_BYTES that is part of the library's code object (every GPU the library runs
+ * on holds its own copy until the process ends); the call makes no hipMalloc, hipFree, event
+ * creation or other allocating call.  The price: a grid of 512 blocks instead of every resident
+ * one, no straggler hand-off (option "coop_steps" is not used), and two limits, beyond which the
+ * call returns RT_ERR_LIMIT: n <= RT_NOALLOC_MAX_RAYS, and a scene whose trees can defer at most
+ * RT_NOALLOC_MAX_STACK nodes per ray (tree depth + 1 for the binary forms; the stand-in scenes need
+ * 24 to 46).  All calls on one GPU share the array: calls that overlap there (two streams, two
+ * contexts, two threads) race; calls on one stream, or otherwise ordered, are fine. */
+#define RT_NOALLOC_MAX_RAYS 268435456u /* 2^28 */
+#define RT_NOALLOC_MAX_STACK 56
+#define RT_NOALLOC_SCRATCH_BYTES 17825792u /* 17 MiB */
+int rt_intersect_stream_noalloc(rt_scene *scene, rt_stream_ray *d_rays, uint32_t *d_hits, uint32_t n,
+                                void *hip_stream);
+
 /* Bvh::occluded_stream / Bvh::occluded1, src/bvh/intersect_stream.rs:200-205,
  * src/bvh/intersect1.rs:7: any hit in [near, far).  occluded[i] = 0/1.  Rays
  * are not modified. */

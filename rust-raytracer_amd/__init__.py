@@ -141,6 +141,7 @@ EXPORTS = {
     "rt_scene_get_flat": (C.c_int, [_vp, _vp, _vp]),
     "rt_intersect_stream": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats)]),
     "rt_intersect_stream_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats), _vp]),
+    "rt_intersect_stream_noalloc": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp]),
     "rt_occluded_stream": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats)]),
     "rt_occluded_stream_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(TraceStats), _vp]),
     "rt_intersect1": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32), C.POINTER(TraceStats)]),
@@ -479,6 +480,10 @@ class Scene:
         _check(_lib.rt_intersect_stream_device(self.h, _vp(rays_ptr), _vp(hits_ptr), int(n),
                                                C.byref(st) if stats else None, _vp(stream)))
         return st.as_dict() if stats else None
+
+    def intersect_stream_noalloc(self, rays_ptr, hits_ptr, n, stream=0):
+        """rt_intersect_stream_noalloc: closest hit on device buffers without any allocation."""
+        _check(_lib.rt_intersect_stream_noalloc(self.h, _vp(rays_ptr), _vp(hits_ptr), int(n), _vp(stream)))
 
     def occluded_stream_device(self, rays_ptr, occ_ptr, n, stream=0, stats=False):
         st = TraceStats()

@@ -153,6 +153,7 @@ struct rt_ctx {
     uint64_t last_max_steps[2] = {0, 0};
     uint64_t last_max_stack[2] = {0, 0};
     rt_depth_stats last_depth[2]{}; // per path depth, render calls with stats
+    unsigned char *na_scratch = nullptr; // this device's copy of g_noalloc_scratch (rt_intersect_stream_noalloc)
 };
 
 struct rt_scene {
@@ -167,6 +168,23 @@ struct rt_scene {
     float bounds_lo[3] = {0, 0, 0};
     float key_scale[3] = {0, 0, 0}; // 1024 / extent, for the Morton sort keys
 };
+
+// ------------------------------------------------------------------------
+// Scratch of rt_intersect_stream_noalloc: ray-fetch counters and the part of the traversal stacks
+// that does not fit in LDS, for a grid of kNaBlocks blocks.  A file-scope device array: it exists
+// once per GPU the library runs on, from module load to process end, and needs no allocation call.
+// Host code never uses the array's name as an address; rt_ctx_create asks the runtime for this
+// device's address of it (hipGetSymbolAddress) and keeps that in the context.
+namespace {
+constexpr unsigned kNaBlocks = 512;                                                   // 2 per CU
+constexpr unsigned kNaOvfEntries = RT_NOALLOC_MAX_STACK - RTC_LDS_STACK_DEPTH;        // per thread
+constexpr size_t kNaFetchBytes = (size_t)kFetchUints * sizeof(unsigned);
+constexpr size_t kNaOvfBytes = (size_t)kNaBlocks * RTC_TRACE_BLOCK * kNaOvfEntries * sizeof(unsigned);
+constexpr size_t kNaBytes = kNaFetchBytes + kNaOvfBytes;
+static_assert(kNaFetchBytes % 256 == 0, "the overflow area starts on a 256-byte boundary");
+static_assert(kNaBytes <= (size_t)RT_NOALLOC_SCRATCH_BYTES, "rtcore.h states the size of the scratch array");
+} // namespace
+static __device__ __align__(256) unsigned char g_noalloc_scratch[kNaBytes];
 
 static int ctx_set_device(rt_ctx *ctx) { HIP_TRY(hipSetDevice(ctx->device)); return RT_OK; }
 
@@ -306,6 +324,13 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
         rc = fail(RT_ERR_NOMEM, "rt_ctx_create: pinned host allocation failed");
     if (rc == RT_OK && hipEventCreateWithFlags(&ctx->counts_ready, hipEventDisableTiming) != hipSuccess)
         rc = fail(RT_ERR_HIP, "rt_ctx_create: hipEventCreate failed");
+    if (rc == RT_OK) { // device_id is current: the address is that of this GPU's copy of the array
+        void *p = nullptr;
+        const hipError_t se = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+        if (se != hipSuccess || !p)
+            rc = fail(RT_ERR_HIP, "rt_ctx_create: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(se));
+        ctx->na_scratch = (unsigned char *)p;
+    }
     if (rc != RT_OK) {
         rt_ctx_destroy(ctx);
         return rc;
@@ -1011,6 +1036,36 @@ extern "C" int rt_occluded_stream_device(rt_scene *sc, const rt_stream_ray *d_ra
     sc->ctx->used = 0;
     return trace_stream_device(sc, true, (rt_stream_ray_dev *)d_rays, nullptr, d_occluded, n, stats,
                                (hipStream_t)hip_stream, true);
+}
+
+extern "C" int rt_intersect_stream_noalloc(rt_scene *sc, rt_stream_ray *d_rays, uint32_t *d_hits, uint32_t n,
+                                           void *hip_stream)
+{
+    if (!sc) return fail(RT_ERR_INVALID, "rt_intersect_stream_noalloc: scene is NULL");
+    if (n && (!d_rays || !d_hits)) return fail(RT_ERR_INVALID, "rt_intersect_stream_noalloc: NULL buffer");
+    if (n > RT_NOALLOC_MAX_RAYS)
+        return fail(RT_ERR_LIMIT, "rt_intersect_stream_noalloc: %u rays, limit is %u per call", n, RT_NOALLOC_MAX_RAYS);
+    if (sc->stack_bound > RT_NOALLOC_MAX_STACK)
+        return fail(RT_ERR_LIMIT,
+                    "rt_intersect_stream_noalloc: this scene's trees can defer %u nodes per ray, the fixed scratch holds %u",
+                    sc->stack_bound, (unsigned)RT_NOALLOC_MAX_STACK);
+    rt_ctx *ctx = sc->ctx;
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    unsigned *fetch = reinterpret_cast<unsigned *>(ctx->na_scratch);
+    unsigned *ovf = reinterpret_cast<unsigned *>(ctx->na_scratch + kNaFetchBytes);
+    // the fetch counters must start at zero; the stack area needs no clearing (entries are written
+    // before they are read)
+    HIP_TRY(hipMemsetAsync(fetch, 0, kNaFetchBytes, s));
+    const unsigned mode = ctx->trav_stream == 5 ? 2u : ctx->trav_stream; // the two-ray form keeps two stacks per lane
+    // no statistics, no launch timing (events are created on demand), no straggler hand-off (its
+    // work stacks are far larger than this scratch)
+    TraceLaunch tl{fetch, ovf, nullptr, ctx->min_active[0], mode, nullptr, 0, nullptr, 0, 0xFFFFFFFFu, 0};
+    launch_trace_stream(false, false, sc->dev, (rt_stream_ray_dev *)d_rays, d_hits, nullptr, n, tl, kNaBlocks, s);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
 }
 
 namespace {
