@@ -39,17 +39,24 @@
 #define RTC_TUNE_ANY3_LDS 16
 #endif
 #ifndef RTC_TUNE_ANY2_WAVES
-#define RTC_TUNE_ANY2_WAVES 5
+#define RTC_TUNE_ANY2_WAVES 7
 #endif
 #ifndef RTC_TUNE_ANY2_LDS
-#define RTC_TUNE_ANY2_LDS RTC_LDS_STACK_DEPTH
+#define RTC_TUNE_ANY2_LDS 16
+#endif
+#ifndef RTC_TUNE_EXT2_WAVES
+#define RTC_TUNE_EXT2_WAVES 6
+#endif
+#ifndef RTC_TUNE_EXT2_LDS
+#define RTC_TUNE_EXT2_LDS RTC_LDS_STACK_DEPTH
 #endif
 // Fewest LDS stack entries any trace kernel keeps per lane: the global overflow area holds the
 // entries beyond that, so it is sized from this value.
 #define RTC_MIN2_(a, b) ((a) < (b) ? (a) : (b))
 #if RTC_TRACE_TUNED
 #define RTC_MIN_LDS_STACK_DEPTH \
-    RTC_MIN2_(RTC_MIN2_(RTC_LDS_STACK_DEPTH, RTC_TUNE_PRIMARY_LDS), RTC_MIN2_(RTC_TUNE_ANY3_LDS, RTC_TUNE_ANY2_LDS))
+    RTC_MIN2_(RTC_MIN2_(RTC_MIN2_(RTC_LDS_STACK_DEPTH, RTC_TUNE_EXT2_LDS), RTC_TUNE_PRIMARY_LDS), \
+              RTC_MIN2_(RTC_TUNE_ANY3_LDS, RTC_TUNE_ANY2_LDS))
 #else
 #define RTC_MIN_LDS_STACK_DEPTH RTC_LDS_STACK_DEPTH
 #endif

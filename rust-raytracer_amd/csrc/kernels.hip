@@ -157,16 +157,21 @@ struct Counters {
 // a global overflow area laid out the same way.
 template <int BLOCK, int LDS_DEPTH>
 struct Stack {
-    unsigned *lds;      // &shared[threadIdx.x]
-    unsigned *ovf;      // &overflow[global thread]
-    unsigned ovf_stride; // threads in the grid
+    unsigned *lds;       // &shared[threadIdx.x]
+    unsigned *ovf_base;  // overflow area (the same for every lane: no per-lane 64-bit pointer is kept)
+    unsigned ovf_lane;   // this stack's column in it
+    unsigned ovf_stride; // columns (stacks in the grid)
     int sp;
+    __device__ __forceinline__ unsigned *ovf_at(int entry) const
+    {
+        return ovf_base + ((size_t)(entry - LDS_DEPTH) * ovf_stride + ovf_lane);
+    }
     __device__ __forceinline__ void push(unsigned v)
     {
         if (sp < LDS_DEPTH)
             lds[sp * BLOCK] = v;
         else
-            ovf[(size_t)(sp - LDS_DEPTH) * ovf_stride] = v;
+            *ovf_at(sp) = v;
         sp++;
     }
     // writes entry `at` without moving the stack pointer
@@ -175,18 +180,18 @@ struct Stack {
         if (at < LDS_DEPTH)
             lds[at * BLOCK] = v;
         else
-            ovf[(size_t)(at - LDS_DEPTH) * ovf_stride] = v;
+            *ovf_at(at) = v;
     }
     __device__ __forceinline__ unsigned load(int at) const
     {
         if (at < LDS_DEPTH) return lds[at * BLOCK];
-        return ovf[(size_t)(at - LDS_DEPTH) * ovf_stride];
+        return *ovf_at(at);
     }
     __device__ __forceinline__ unsigned pop()
     {
         sp--;
         if (sp < LDS_DEPTH) return lds[sp * BLOCK];
-        return ovf[(size_t)(sp - LDS_DEPTH) * ovf_stride];
+        return *ovf_at(sp);
     }
     // pop() whose (rare) read of the overflow area waits for itself.  A load the compiler can see would
     // make it wait for every vector memory operation at the point where the paths join -- also for
@@ -196,7 +201,7 @@ struct Stack {
         sp--;
         if (sp < LDS_DEPTH) return lds[sp * BLOCK];
         unsigned v;
-        const unsigned *p = ovf + (size_t)(sp - LDS_DEPTH) * ovf_stride;
+        const unsigned *p = ovf_at(sp);
         asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
         return v;
     }
@@ -588,6 +593,11 @@ __device__ __forceinline__ SlabRay slab_ray(const LaneState &s)
 {
     return SlabRay{s.r.rd, s.ordx, s.ordy, s.ordz, s.negx, s.negy, s.negz};
 }
+// the wide forms do not keep o * (1/d) per ray: three multiplications per node instead of three registers
+__device__ __forceinline__ SlabRay slab_ray_lean(const LaneState &s)
+{
+    return SlabRay{s.r.rd, s.r.o.x * s.r.rd.x, s.r.o.y * s.r.rd.y, s.r.o.z * s.r.rd.z, s.negx, s.negy, s.negz};
+}
 __device__ __forceinline__ SlabRay slab_ray(const RayRegs &r)
 {
     return SlabRay{r.rd, r.o.x * r.rd.x, r.o.y * r.rd.y, r.o.z * r.rd.z, (__float_as_uint(r.rd.x) >> 31) != 0,
@@ -689,45 +699,42 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
 {
     const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
     RayRegs &r = s.r;
-    // cur: unit << 2 | triangles of the item being visited; tri / tri_end: units of the leaf's
-    // triangles still to test
-    unsigned cur = s.cur, tri = s.tri, tri_end = s.tri_end;
+    // cur: reference (unit << 2 | triangles) of the item being visited; leaf (kept in s.tri): unit << 2 |
+    // triangles still to test of the leaf the ray is in, the encoding of a reference, so that entering
+    // a leaf is one move
+    unsigned cur = s.cur, leaf = s.tri;
     unsigned steps = s.steps;
 
-    while (cur != kDone && (steps < max_steps || tri < tri_end)) {
+    while (cur != kDone && (steps < max_steps || (leaf & 3u))) {
         steps++;
-        if ((cur & 3u) && tri >= tri_end) { // entering a leaf
-            tri = cur >> 2;
-            tri_end = tri + kUnitsPerItem * (cur & 3u);
-        }
-        const bool in_leaf = tri < tri_end;
-        const float4 *p = items + (in_leaf ? tri : cur >> 2);
+        if ((cur & 3u) && !(leaf & 3u)) leaf = cur; // entering a leaf
+        const bool in_leaf = (leaf & 3u) != 0;
+        const float4 *p = items + ((in_leaf ? leaf : cur) >> 2);
         float4 a0, a1, a2;
         load_item(p, a0, a1, a2);
         bool need_pop = false;
         if (!in_leaf) {
-            need_pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray(s), r.near_t, r.far_t, st, cur);
+            need_pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray_lean(s), r.near_t, r.far_t, st, cur);
         } else {
             const float t = tri_test(a0, a1, make_float2(a2.x, a2.y), r.o, r.d);
-            tri += kUnitsPerItem;
+            leaf += (kUnitsPerItem << 2) - 1u; // the next triangle, one fewer to go
             if (t >= r.near_t && t < r.far_t) {
                 if (ANYHIT) {
                     s.hit = 1u;
                     cur = kDone;
-                    tri = tri_end;
+                    leaf = 0;
                 } else {
                     r.far_t = t;
                     s.hit = __float_as_uint(a2.y);
                 }
             }
-            need_pop = (tri >= tri_end) && (cur != kDone);
+            need_pop = !(leaf & 3u) && (cur != kDone);
         }
         if (need_pop) cur = st.sp ? st.pop() : kDone;
         if ((unsigned)__popcll(__ballot(true)) < min_active) break;
     }
     s.cur = cur;
-    s.tri = tri;
-    s.tri_end = tri_end;
+    s.tri = leaf;
     s.steps = steps;
 }
 // While-while form on the quantized 4-wide tree (coherent rays): all lanes walk
@@ -843,9 +850,10 @@ __device__ __forceinline__ void coop_finish_wide(const SceneDev &sc, STATE &s, S
     unsigned count = 0; // wave-uniform
     {
         unsigned *lds_p = st.lds - (threadIdx.x & 63) + p; // column of lane p
-        unsigned *ovf_p = st.ovf - (size_t)(threadIdx.x & 63) + p;
+        const unsigned col_p = st.ovf_lane - (threadIdx.x & 63) + p;
         for (int e = (int)lane; e < sp_p; e += 64) {
-            const unsigned ref = e < LDS_DEPTH ? lds_p[e * BLOCK] : ovf_p[(size_t)(e - LDS_DEPTH) * st.ovf_stride];
+            const unsigned ref =
+                e < LDS_DEPTH ? lds_p[e * BLOCK] : st.ovf_base[(size_t)(e - LDS_DEPTH) * st.ovf_stride + col_p];
             work[e] = CoopItem{ref, -__builtin_inff()};
         }
         count = (unsigned)sp_p;
@@ -1004,13 +1012,13 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, St
     unsigned count = 0; // wave-uniform
     {
         unsigned *lds_p = st.lds - (threadIdx.x & 63) + p;            // column of lane p
-        unsigned *ovf_p = st.ovf - (size_t)(threadIdx.x & 63) + p;
+        const unsigned col_p = st.ovf_lane - (threadIdx.x & 63) + p;
         for (int e = (int)lane; e < sp_p; e += 64) {
             unsigned ref;
             if (e < LDS_DEPTH)
                 ref = lds_p[e * BLOCK];
             else
-                ref = ovf_p[(size_t)(e - LDS_DEPTH) * st.ovf_stride];
+                ref = st.ovf_base[(size_t)(e - LDS_DEPTH) * st.ovf_stride + col_p];
             work[e] = CoopItem{ref, -__builtin_inff()};
         }
         count = (unsigned)sp_p;
@@ -1268,10 +1276,11 @@ struct QueueIO { // render pipeline queues
 struct PrimaryIO; // depth-0 closest-hit launches that make their own camera rays (defined below the camera code)
 
 // Resident waves per SIMD the compiler allocates registers for, and LDS stack entries per lane, by
-// kernel.  The coherent launches gain from more waves (measured on the Sponza-class frame: depth-0
-// extend +3.5 % at 6 waves, depth-0 connect +5 % at 8 waves with 16 LDS entries, a few registers
-// spilled in both); the stepwise forms for incoherent rays lose far more to the tighter register
-// budget than they gain (San-Miguel-class extend -19 % at 6).
+// kernel (measured side by side on one GPU).  Every form is partly latency bound -- an iteration ends in a wait for
+// the slowest gather of the wave -- so each kernel runs at the highest occupancy its loop reaches
+// without spilling inside the loop: depth-0 extend 6 waves, depth-0 connect (while-while any-hit) 8
+// with 16 LDS entries, stepwise extend on the wide tree 6 (5 before the ray state was trimmed: +2 %
+// on the San-Miguel-class frame; at 7 its spills cost 25 %), stepwise any-hit 7 with 16 LDS entries.
 template <bool ANYHIT, bool STATS, int MODE, class IO>
 struct TraceTune {
     static constexpr int waves = RTC_TRACE_WAVES_PER_SIMD;
@@ -1303,6 +1312,11 @@ struct TraceTune<true, false, 2, QueueIO> {
     static constexpr int waves = RTC_TUNE_ANY2_WAVES;
     static constexpr int lds_depth = RTC_TUNE_ANY2_LDS;
 };
+template <>
+struct TraceTune<false, false, 2, QueueIO> {
+    static constexpr int waves = RTC_TUNE_EXT2_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_EXT2_LDS;
+};
 #endif
 
 template <bool ANYHIT, bool STATS, int MODE, class IO>
@@ -1312,11 +1326,13 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
     constexpr int kDepth = TraceTune<ANYHIT, STATS, MODE, IO>::lds_depth;
     constexpr bool kWide = MODE == 2 || MODE == 3; // forms on the quantized 4-wide tree
     __shared__ unsigned lds_stack[kDepth * kBlock];
+    __shared__ unsigned lds_index[kBlock]; // queue position of the lane's ray: needed again only when it retires
     const unsigned n = n_ptr ? *n_ptr : n_val;
     const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
     Stack<kBlock, kDepth> st;
     st.lds = lds_stack + threadIdx.x;
-    st.ovf = tl.ovf + gtid;
+    st.ovf_base = tl.ovf;
+    st.ovf_lane = gtid;
     st.ovf_stride = gridDim.x * kBlock;
     st.sp = 0;
     Counters cnt{0, 0, 0, 0, 0, 0};
@@ -1366,7 +1382,8 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
                     const float dz = fabsf(loaded.d.z) < tiny ? copysignf(tiny, loaded.d.z) : loaded.d.z;
                     loaded.rd = v3(1.f / dx, 1.f / dy, 1.f / dz);
                 }
-                lane_begin(s, kWide ? sc.wroot_ref : sc.root_ref, loaded, ray);
+                lane_begin(s, kWide ? sc.wroot_ref : sc.root_ref, loaded, 0u);
+                lds_index[threadIdx.x] = ray;
                 st.sp = 0;
                 // A ray with a NaN or infinite origin or direction component cannot be accepted by
                 // the triangle test (its determinant is not finite), but NaN slab distances drop every
@@ -1403,8 +1420,8 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
 
         // ---- stragglers: rays that used up their step budget are finished by the whole wave
         {
-            unsigned long long parked =
-                __ballot(s.have_ray && s.cur != kDone && s.steps >= tl.coop_steps && s.tri >= s.tri_end);
+            const bool inside_leaf = MODE == 2 ? (s.tri & 3u) != 0 : s.tri < s.tri_end;
+            unsigned long long parked = __ballot(s.have_ray && s.cur != kDone && s.steps >= tl.coop_steps && !inside_leaf);
             CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
             while (parked != 0) {
                 const unsigned p = (unsigned)__ffsll((long long)parked) - 1u;
@@ -1418,6 +1435,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
 
         // ---- retire finished rays
         if (s.have_ray && s.cur == kDone) {
+            s.index = lds_index[threadIdx.x];
             io.template store<ANYHIT>(s);
             s.have_ray = false;
             if (STATS) {
@@ -1544,7 +1562,8 @@ __global__ __launch_bounds__(kBlock, RTC_DUAL_WAVES_PER_SIMD) void trace_kernel_
 #pragma unroll
     for (int k = 0; k < 2; k++) { // the two stacks of a lane: separate LDS planes, interleaved overflow columns
         st[k].lds = lds_stack + k * kDualLdsDepth * kBlock + threadIdx.x;
-        st[k].ovf = tl.ovf + (size_t)k * threads + gtid;
+        st[k].ovf_base = tl.ovf;
+        st[k].ovf_lane = k * threads + gtid;
         st[k].ovf_stride = 2u * threads;
         st[k].sp = 0;
     }
