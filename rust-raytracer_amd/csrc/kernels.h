@@ -33,7 +33,7 @@
 #define RTC_TUNE_PRIMARY_LDS RTC_LDS_STACK_DEPTH
 #endif
 #ifndef RTC_TUNE_ANY3_WAVES
-#define RTC_TUNE_ANY3_WAVES 8
+#define RTC_TUNE_ANY3_WAVES 7
 #endif
 #ifndef RTC_TUNE_ANY3_LDS
 #define RTC_TUNE_ANY3_LDS 16

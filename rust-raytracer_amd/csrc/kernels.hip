@@ -756,13 +756,13 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
             bool pop;
             if (__ballot(cur != ucur) == 0) { // every lane still in this loop is at node ucur
                 const u32x16 n = scalar_load64(items + (ucur >> 2));
-                pop = qwide_step<ANYHIT>(f4_of(n, 0), f4_of(n, 4), f4_of(n, 8), slab_ray(s), r.near_t, r.far_t, st, cur);
+                pop = qwide_step<ANYHIT>(f4_of(n, 0), f4_of(n, 4), f4_of(n, 8), slab_ray_lean(s), r.near_t, r.far_t, st, cur);
             } else {
                 const float4 *q = items + (cur >> 2);
                 const float4 a0 = q[0];
                 const float4 a1 = q[1];
                 const float4 a2 = q[2];
-                pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray(s), r.near_t, r.far_t, st, cur);
+                pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray_lean(s), r.near_t, r.far_t, st, cur);
             }
             if (pop) cur = st.sp ? st.pop() : kDone;
         }
@@ -1278,7 +1278,7 @@ struct PrimaryIO; // depth-0 closest-hit launches that make their own camera ray
 // Resident waves per SIMD the compiler allocates registers for, and LDS stack entries per lane, by
 // kernel (measured side by side on one GPU).  Every form is partly latency bound -- an iteration ends in a wait for
 // the slowest gather of the wave -- so each kernel runs at the highest occupancy its loop reaches
-// without spilling inside the loop: depth-0 extend 6 waves, depth-0 connect (while-while any-hit) 8
+// without spilling inside the loop: depth-0 extend 6 waves, depth-0 connect (while-while any-hit) 7
 // with 16 LDS entries, stepwise extend on the wide tree 6 (5 before the ray state was trimmed: +2 %
 // on the San-Miguel-class frame; at 7 its spills cost 25 %), stepwise any-hit 7 with 16 LDS entries.
 template <bool ANYHIT, bool STATS, int MODE, class IO>
