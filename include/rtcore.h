@@ -151,7 +151,9 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       wave (0 = never; default 4096).  Rays handled that way keep their exact
  *                       hit distance; their visit counters and the id on an
  *                       exact-distance tie may differ from the single-lane walk.
- *   "min_active"        1..64, a wave fetches new rays when fewer lanes are busy (default 40)
+ *   "min_active"        1..64, a wave fetches new rays when fewer lanes are busy (default 40);
+ *   "min_active_depth0" the same for the depth-0 launches of rt_render (default 20: their rays
+ *                       are coherent and a refill costs more than a few idle lanes)
  *   "traversal_depth0", "traversal_deep", "traversal_stream"   traversal form of the
  *                       depth-0 launches of rt_render, of its deeper launches, and of the
  *                       stream entry points: 0 = while-while loop on the binary tree, 1 = one
@@ -168,7 +170,12 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       ties, no visit counters, and 1/d is bounded as in the reference's
  *                       packet rays (src/simd_ray.rs:46-47) so that axis-parallel rays are
  *                       culled properly.  Calls that ask for visit counters always run form
- *                       0 or 1.
+ *                       0 or 1.  "traversal_deep" and "traversal_stream" also take two
+ *                       experimental variants of form 2 with the same results (kept for
+ *                       measurements, neither is faster): 5 = two rays per lane, the loads of
+ *                       one issued behind the arithmetic of the other; 6 = a lane walks
+ *                       nodes and tests the triangles of the last leaf it reached side by
+ *                       side, one node and one triangle per iteration.
  *   "fuse_primary"      0/1 (default 1): depth 0 of rt_render without ray and PathInfo queues;
  *                       the extend launch makes the camera rays itself.  Same image bit for
  *                       bit; not used by calls that ask for visit counters.

@@ -50,13 +50,25 @@
 #ifndef RTC_TUNE_EXT2_LDS
 #define RTC_TUNE_EXT2_LDS RTC_LDS_STACK_DEPTH
 #endif
+#ifndef RTC_TUNE_EXT6_WAVES
+#define RTC_TUNE_EXT6_WAVES 5
+#endif
+#ifndef RTC_TUNE_EXT6_LDS
+#define RTC_TUNE_EXT6_LDS RTC_LDS_STACK_DEPTH
+#endif
+#ifndef RTC_TUNE_ANY6_WAVES
+#define RTC_TUNE_ANY6_WAVES 6
+#endif
+#ifndef RTC_TUNE_ANY6_LDS
+#define RTC_TUNE_ANY6_LDS 16
+#endif
 // Fewest LDS stack entries any trace kernel keeps per lane: the global overflow area holds the
 // entries beyond that, so it is sized from this value.
 #define RTC_MIN2_(a, b) ((a) < (b) ? (a) : (b))
 #if RTC_TRACE_TUNED
 #define RTC_MIN_LDS_STACK_DEPTH \
     RTC_MIN2_(RTC_MIN2_(RTC_MIN2_(RTC_LDS_STACK_DEPTH, RTC_TUNE_EXT2_LDS), RTC_TUNE_PRIMARY_LDS), \
-              RTC_MIN2_(RTC_TUNE_ANY3_LDS, RTC_TUNE_ANY2_LDS))
+              RTC_MIN2_(RTC_MIN2_(RTC_TUNE_ANY3_LDS, RTC_TUNE_ANY2_LDS), RTC_MIN2_(RTC_TUNE_EXT6_LDS, RTC_TUNE_ANY6_LDS)))
 #else
 #define RTC_MIN_LDS_STACK_DEPTH RTC_LDS_STACK_DEPTH
 #endif

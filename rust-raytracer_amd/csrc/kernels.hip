@@ -737,6 +737,97 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
     s.tri = leaf;
     s.steps = steps;
 }
+// The items of one iteration of traverse_wide_split(): a triangle (40 bytes used) for the lanes in
+// tmask and a node for the lanes in nmask.  The six loads are always issued -- lanes without an
+// item of a kind are masked off through exec, not by a branch -- and one wait covers them all.
+__device__ __forceinline__ void load_tri_and_node(const float4 *pt, unsigned long long tmask, const float4 *pn,
+                                                  unsigned long long nmask, float4 &t0, float4 &t1, float2 &t2,
+                                                  float4 &n0, float4 &n1, float4 &n2)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %6, exec\n\t"
+                 "s_mov_b64 exec, %9\n\t"
+                 "global_load_dwordx4 %0, %7, off\n\t"
+                 "global_load_dwordx4 %1, %7, off offset:16\n\t"
+                 "global_load_dwordx2 %2, %7, off offset:32\n\t"
+                 "s_mov_b64 exec, %10\n\t"
+                 "global_load_dwordx4 %3, %8, off\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:16\n\t"
+                 "global_load_dwordx4 %5, %8, off offset:32\n\t"
+                 "s_mov_b64 exec, %6\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&s"(saved)
+                 : "v"(pt), "v"(pn), "s"(tmask), "s"(nmask)
+                 : "memory");
+}
+
+// Stepwise traversal with the node walk and the triangle tests of a ray side by side (form 6).
+//
+// In traverse_wide_steps() a lane is either at a node or inside a leaf, and since the lanes of a
+// wave of incoherent rays are never all at the same kind of item every iteration runs the node
+// code and the triangle code, each for the lanes that need it: on the San-Miguel-class bounce
+// rays (about 30 nodes and 32 triangles per ray) 28 of 64 lanes are active per instruction.  Here
+// a lane keeps BOTH going: when the walk reaches a leaf the leaf is handed to the lane's triangle
+// cursor and the walk goes on with the next deferred node at once; an iteration loads and tests one
+// triangle of the pending leaf and one node.  The instructions per iteration are the same, the
+// iterations per ray drop from nodes + triangles towards the larger of the two.  The price: a node
+// visited while a leaf is pending is tested against a far that the leaf's triangles may still shorten
+// (a few wasted visits after the leaf that holds the hit), and the results of a node and a triangle
+// live in registers at the same time.  The walk waits when it reaches another leaf before the
+// triangle cursor is free.  Closest hits do not depend on the order (ids on exact-distance ties
+// may, as between any two forms).
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ void traverse_wide_split(const SceneDev &sc, LaneState &s, STACK &st, unsigned min_active,
+                                                    unsigned max_steps)
+{
+    const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
+    RayRegs &r = s.r;
+    // cur: the walk's item (a node, or a leaf waiting for the triangle cursor, or kDone);
+    // leaf: unit << 2 | triangles still to test of the pending leaf (0 = none)
+    unsigned cur = s.cur, leaf = s.tri;
+    unsigned steps = s.steps;
+
+    // past the step budget the walk stands still and only the pending leaf is finished, so that a
+    // ray is handed to the wave-cooperative finisher with nothing but `cur` and its stack
+    while ((leaf & 3u) || (cur != kDone && steps < max_steps)) {
+        const bool budget = steps < max_steps;
+        steps++;
+        const bool do_tri = (leaf & 3u) != 0;
+        const bool do_node = budget && !(cur & 3u); // kDone has its low bits set
+        float4 t0, t1, n0, n1, n2;
+        float2 t2;
+        load_tri_and_node(items + (leaf >> 2), __ballot(do_tri), items + (cur >> 2), __ballot(do_node), t0, t1, t2, n0,
+                          n1, n2);
+        if (do_tri) {
+            const float t = tri_test(t0, t1, t2, r.o, r.d);
+            leaf += (kUnitsPerItem << 2) - 1u; // the next triangle, one fewer to go
+            if (t >= r.near_t && t < r.far_t) {
+                if (ANYHIT) {
+                    s.hit = 1u;
+                    cur = kDone;
+                    leaf = 0;
+                } else {
+                    r.far_t = t;
+                    s.hit = __float_as_uint(t2.y);
+                }
+            }
+        }
+        bool need_pop = false;
+        if (do_node && (!ANYHIT || cur != kDone))
+            need_pop = qwide_step<ANYHIT>(n0, n1, n2, slab_ray_lean(s), r.near_t, r.far_t, st, cur);
+        // a leaf reached by the walk goes to the triangle cursor as soon as that is free
+        if (budget && !need_pop && cur != kDone && (cur & 3u) && !(leaf & 3u)) {
+            leaf = cur;
+            need_pop = true;
+        }
+        if (need_pop) cur = st.sp ? st.pop() : kDone;
+        if ((unsigned)__popcll(__ballot(true)) < min_active) break;
+    }
+    s.cur = cur;
+    s.tri = leaf;
+    s.steps = steps;
+}
+
 // While-while form on the quantized 4-wide tree (coherent rays): all lanes walk
 // wide nodes until each has reached a leaf or finished, then the leaves are
 // tested; see traverse() for the loop and traverse_wide_steps() for the node.
@@ -1317,6 +1408,16 @@ struct TraceTune<false, false, 2, QueueIO> {
     static constexpr int waves = RTC_TUNE_EXT2_WAVES;
     static constexpr int lds_depth = RTC_TUNE_EXT2_LDS;
 };
+template <>
+struct TraceTune<false, false, 6, QueueIO> {
+    static constexpr int waves = RTC_TUNE_EXT6_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_EXT6_LDS;
+};
+template <>
+struct TraceTune<true, false, 6, QueueIO> {
+    static constexpr int waves = RTC_TUNE_ANY6_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_ANY6_LDS;
+};
 #endif
 
 template <bool ANYHIT, bool STATS, int MODE, class IO>
@@ -1324,7 +1425,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
                                                       TraceLaunch tl)
 {
     constexpr int kDepth = TraceTune<ANYHIT, STATS, MODE, IO>::lds_depth;
-    constexpr bool kWide = MODE == 2 || MODE == 3; // forms on the quantized 4-wide tree
+    constexpr bool kWide = MODE == 2 || MODE == 3 || MODE == 6; // forms on the quantized 4-wide tree
     __shared__ unsigned lds_stack[kDepth * kBlock];
     __shared__ unsigned lds_index[kBlock]; // queue position of the lane's ray: needed again only when it retires
     const unsigned n = n_ptr ? *n_ptr : n_val;
@@ -1345,6 +1446,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
 
     LaneState s;
     s.cur = kDone;
+    s.tri = s.tri_end = 0; // no leaf pending: form 6 walks a lane for as long as it has one
     s.have_ray = false;
 
     while (true) {
@@ -1415,12 +1517,14 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             traverse_wide<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else if (MODE == 2)
             traverse_wide_steps<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+        else if (MODE == 6)
+            traverse_wide_split<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else
             traverse_steps<ANYHIT, STATS, (MODE == 4)>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
 
         // ---- stragglers: rays that used up their step budget are finished by the whole wave
         {
-            const bool inside_leaf = MODE == 2 ? (s.tri & 3u) != 0 : s.tri < s.tri_end;
+            const bool inside_leaf = (MODE == 2 || MODE == 6) ? (s.tri & 3u) != 0 : s.tri < s.tri_end;
             unsigned long long parked = __ballot(s.have_ray && s.cur != kDone && s.steps >= tl.coop_steps && !inside_leaf);
             CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
             while (parked != 0) {
@@ -1433,8 +1537,8 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             }
         }
 
-        // ---- retire finished rays
-        if (s.have_ray && s.cur == kDone) {
+        // ---- retire finished rays (form 6: the walk can be done while the last leaf is still pending)
+        if (s.have_ray && s.cur == kDone && !(MODE == 6 && (s.tri & 3u))) {
             s.index = lds_index[threadIdx.x];
             io.template store<ANYHIT>(s);
             s.have_ray = false;
@@ -2197,9 +2301,14 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
                                n_val, tl);
         return;
     }
-    if ((tl.mode == 2 || tl.mode == 3) && !stats && sc.witems) {
+    if ((tl.mode == 2 || tl.mode == 3 || tl.mode == 6) && !stats && sc.witems) {
         // 4-wide tree, no visit counters in these forms
-        if (tl.mode == 2) {
+        if (tl.mode == 6) {
+            if (anyhit)
+                launch_one<true, false, 6, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+            else
+                launch_one<false, false, 6, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+        } else if (tl.mode == 2) {
             if (anyhit)
                 launch_one<true, false, 2, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
             else

@@ -113,7 +113,11 @@ struct rt_ctx {
     DevBuf coop;  // wave-private work stacks of the cooperative straggler path
     unsigned coop_cap = 2048;    // entries per wave
     unsigned coop_steps = 4096;  // a ray is handed to its whole wave after this many loop iterations
-    unsigned min_active[2] = {40, 40}; // [0] closest-hit, [1] any-hit launches
+    // refill threshold [depth 0 of rt_render: 0, everything else: 1][closest-hit: 0, any-hit: 1].  The
+    // depth-0 launches run the while-while forms on coherent rays, where a refill (for the fused
+    // primary launch: making the camera rays) costs more than a few idle lanes do: 20 is 4 % faster than
+    // 40 there; the stepwise launches on incoherent rays lose 1-2 % below 40.
+    unsigned min_active[2][2] = {{20, 20}, {40, 40}};
     // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
     // while-while form wins), [1] for deeper launches and the stream entry points
     unsigned fast_tree_buckets = 32; // >= 2: the fast forms get a tree from the search builder with that many buckets; 0: the reference's tree
@@ -274,7 +278,12 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_MIN_ACTIVE")) {
         int v = atoi(env);
-        if (v >= 1 && v <= 64) ctx->min_active[0] = ctx->min_active[1] = (unsigned)v;
+        if (v >= 1 && v <= 64)
+            ctx->min_active[0][0] = ctx->min_active[0][1] = ctx->min_active[1][0] = ctx->min_active[1][1] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_MIN_ACTIVE_DEPTH0")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64) ctx->min_active[0][0] = ctx->min_active[0][1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL")) {
         int v = atoi(env);
@@ -283,7 +292,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_FUSE_PRIMARY")) ctx->fuse_primary = atoi(env) ? 1u : 0u;
     if (const char *env = getenv("RTCORE_TRAVERSAL_STREAM")) {
         int v = atoi(env);
-        if (v >= 0 && v <= 5) ctx->trav_stream = (unsigned)v;
+        if (v >= 0 && v <= 6) ctx->trav_stream = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
         int v = atoi(env);
@@ -291,7 +300,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP")) {
         int v = atoi(env);
-        if ((v >= 0 && v <= 3) || v == 5) ctx->trav_mode[1] = (unsigned)v;
+        if ((v >= 0 && v <= 3) || v == 5 || v == 6) ctx->trav_mode[1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_SORT_EXTEND_FROM")) ctx->sort_from_depth[0] = (unsigned)atoi(env);
     if (const char *env = getenv("RTCORE_SORT_CONNECT_FROM")) ctx->sort_from_depth[1] = (unsigned)atoi(env);
@@ -305,11 +314,11 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_MIN_ACTIVE_EXTEND")) {
         int v = atoi(env);
-        if (v >= 1 && v <= 64) ctx->min_active[0] = (unsigned)v;
+        if (v >= 1 && v <= 64) ctx->min_active[0][0] = ctx->min_active[1][0] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_MIN_ACTIVE_CONNECT")) {
         int v = atoi(env);
-        if (v >= 1 && v <= 64) ctx->min_active[1] = (unsigned)v;
+        if (v >= 1 && v <= 64) ctx->min_active[0][1] = ctx->min_active[1][1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_COOP_CAP")) {
         int v = atoi(env);
@@ -392,16 +401,18 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
     if (n == "coop_steps") {
         ctx->coop_steps = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
     } else if (n == "min_active" && in(1, 64)) {
-        ctx->min_active[0] = ctx->min_active[1] = (unsigned)value;
+        ctx->min_active[1][0] = ctx->min_active[1][1] = (unsigned)value;
+    } else if (n == "min_active_depth0" && in(1, 64)) {
+        ctx->min_active[0][0] = ctx->min_active[0][1] = (unsigned)value;
     } else if (n == "fuse_primary" && in(0, 1)) {
         ctx->fuse_primary = (unsigned)value;
     } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
         ctx->fast_tree_buckets = (unsigned)value;
-    } else if (n == "traversal_stream" && in(0, 5)) {
+    } else if (n == "traversal_stream" && in(0, 6)) {
         ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
         ctx->trav_mode[0] = (unsigned)value;
-    } else if (n == "traversal_deep" && (in(0, 3) || value == 5)) {
+    } else if (n == "traversal_deep" && (in(0, 3) || value == 5 || value == 6)) {
         ctx->trav_mode[1] = (unsigned)value;
     } else if (n == "sort_extend_from" && in(0, 0xFFFFFFFFll)) {
         ctx->sort_from_depth[0] = (unsigned)value;
@@ -993,7 +1004,7 @@ static int trace_stream_device(rt_scene *sc, bool anyhit, rt_stream_ray_dev *d_r
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(ctx->fetch.p, 0, kFetchUints * sizeof(unsigned), s));
     TraceLaunch tl{(unsigned *)ctx->fetch.p, (unsigned *)ctx->ovf.p, (StatsDev *)ctx->dstats.p + (anyhit ? 1 : 0),
-                   ctx->min_active[anyhit ? 1 : 0], mode, nullptr, 0, nullptr, 0, 0, 0};
+                   ctx->min_active[1][anyhit ? 1 : 0], mode, nullptr, 0, nullptr, 0, 0, 0};
     fill_coop(ctx, sc, tl);
     launch_trace_stream(anyhit, want, sc->dev, d_rays, d_hits, d_occ, n, tl, ctx->max_blocks, s);
     HIP_TRY(hipGetLastError());
@@ -1062,7 +1073,7 @@ extern "C" int rt_intersect_stream_noalloc(rt_scene *sc, rt_stream_ray *d_rays, 
     const unsigned mode = ctx->trav_stream == 5 ? 2u : ctx->trav_stream; // the two-ray form keeps two stacks per lane
     // no statistics, no launch timing (events are created on demand), no straggler hand-off (its
     // work stacks are far larger than this scratch)
-    TraceLaunch tl{fetch, ovf, nullptr, ctx->min_active[0], mode, nullptr, 0, nullptr, 0, 0xFFFFFFFFu, 0};
+    TraceLaunch tl{fetch, ovf, nullptr, ctx->min_active[1][0], mode, nullptr, 0, nullptr, 0, 0xFFFFFFFFu, 0};
     launch_trace_stream(false, false, sc->dev, (rt_stream_ray_dev *)d_rays, d_hits, nullptr, n, tl, kNaBlocks, s);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1461,7 +1472,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
             for (uint32_t b = 0; b < nb; b++) {
                 rc = timed_begin(ctx, 0, s, &slot);
                 if (rc != RT_OK) return rc;
-                TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[0],
+                TraceLaunch tle{fetch + (size_t)(2 * b) * kFetchUints, ovf, dstats, ctx->min_active[b == 0 ? 0 : 1][0],
                                 ctx->trav_mode[b == 0 ? 0 : 1], perm_extend, perm_extend_n, nullptr, 0, 0, b};
                 fill_coop(ctx, sc, tle);
                 if (fused && b == 0)
@@ -1548,7 +1559,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
 
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
-                TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[1],
+                TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[b == 0 ? 0 : 1][1],
                                 ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, perm_connect_n, nullptr, 0, 0, b};
                 fill_coop(ctx, sc, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,

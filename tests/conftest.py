@@ -34,7 +34,7 @@ def scenes():
 
 
 # Library defaults of every option a test may change, and what the exact configuration sets on top.
-OPTION_DEFAULTS = {"coop_steps": 4096, "min_active": 40, "traversal_depth0": 3, "traversal_deep": 2,
+OPTION_DEFAULTS = {"coop_steps": 4096, "min_active": 40, "min_active_depth0": 20, "traversal_depth0": 3, "traversal_deep": 2,
                    "traversal_stream": 1, "fuse_primary": 1, "sort_extend_from": 0xFFFFFFFF,
                    "sort_connect_from": 1, "sort_bits": 21, "timing": 1}
 EXACT_OPTIONS = {"coop_steps": 0, "traversal_depth0": 0, "traversal_deep": 1, "traversal_stream": 1}
