@@ -29,8 +29,19 @@
 #ifndef RTC_TUNE_PRIMARY_WAVES
 #define RTC_TUNE_PRIMARY_WAVES 6
 #endif
+// 1: the kernel keeps a 16-bit entry distance beside every LDS stack entry (6 bytes per entry: 16
+// entries in the LDS that 24 plain ones took) and drops deferred nodes a found hit has put out of
+// reach when it pops them.  On for the while-while closest-hit kernel of depth 0 (-3 % on all three
+// workloads); off for the stepwise kernel of the deeper launches, where the longer push and pop
+// paths cost more than the skipped items save (+4 % San-Miguel-class, +9 % dragon-class).
+#ifndef RTC_TUNE_PRIMARY_DIST
+#define RTC_TUNE_PRIMARY_DIST 1
+#endif
+#ifndef RTC_TUNE_EXT2_DIST
+#define RTC_TUNE_EXT2_DIST 0
+#endif
 #ifndef RTC_TUNE_PRIMARY_LDS
-#define RTC_TUNE_PRIMARY_LDS RTC_LDS_STACK_DEPTH
+#define RTC_TUNE_PRIMARY_LDS (RTC_TUNE_PRIMARY_DIST ? 16 : RTC_LDS_STACK_DEPTH)
 #endif
 #ifndef RTC_TUNE_ANY3_WAVES
 #define RTC_TUNE_ANY3_WAVES 7
@@ -48,7 +59,7 @@
 #define RTC_TUNE_EXT2_WAVES 6
 #endif
 #ifndef RTC_TUNE_EXT2_LDS
-#define RTC_TUNE_EXT2_LDS RTC_LDS_STACK_DEPTH
+#define RTC_TUNE_EXT2_LDS (RTC_TUNE_EXT2_DIST ? 16 : RTC_LDS_STACK_DEPTH)
 #endif
 #ifndef RTC_TUNE_EXT6_WAVES
 #define RTC_TUNE_EXT6_WAVES 5

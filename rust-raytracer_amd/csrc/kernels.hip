@@ -155,9 +155,22 @@ struct Counters {
 // [entry][thread] order (lane l and lane l+32 hit the same bank in different
 // halves of a ds_read_b32, so accesses are conflict-free); deeper entries go to
 // a global overflow area laid out the same way.
-template <int BLOCK, int LDS_DEPTH>
+//
+// DIST: the LDS entries also carry the entry distance of their box, as the upper 16 bits of the f32
+// (rounded towards zero, i.e. down: conservative), so that a closest-hit walk can drop a deferred
+// node that a hit found since has put out of reach without loading it.  The distances of entries
+// 2k and 2k+1 share the lane's word k of a second set of planes right behind the entry planes
+// (same [plane][thread] layout, addressed from the same base: no second per-lane pointer).  Entries
+// in the overflow area carry none (they read as distance 0: never dropped).
+template <int BLOCK, int LDS_DEPTH, bool DIST = false>
 struct Stack {
+    static constexpr bool kDist = DIST;
     unsigned *lds;       // &shared[threadIdx.x]
+    static constexpr int kLdsWords = LDS_DEPTH + (DIST ? (LDS_DEPTH + 1) / 2 : 0); // per lane
+    __device__ __forceinline__ unsigned short *dist_at(int entry) const
+    {
+        return reinterpret_cast<unsigned short *>(lds + (LDS_DEPTH + (entry >> 1)) * BLOCK) + (entry & 1);
+    }
     unsigned *ovf_base;  // overflow area (the same for every lane: no per-lane 64-bit pointer is kept)
     unsigned ovf_lane;   // this stack's column in it
     unsigned ovf_stride; // columns (stacks in the grid)
@@ -181,6 +194,27 @@ struct Stack {
             lds[at * BLOCK] = v;
         else
             *ovf_at(at) = v;
+    }
+    // entry `at` with the sort key of its box (entry-distance bits, slot in the two lowest)
+    __device__ __forceinline__ void store_keyed(int at, unsigned v, unsigned key)
+    {
+        if (at < LDS_DEPTH) {
+            lds[at * BLOCK] = v;
+            if (DIST) *dist_at(at) = (unsigned short)(key >> 16);
+        } else {
+            *ovf_at(at) = v;
+        }
+    }
+    // pop() that also gives a lower bound of the entry distance the entry was pushed with
+    __device__ __forceinline__ unsigned pop_keyed(float &tnear)
+    {
+        sp--;
+        if (sp < LDS_DEPTH) {
+            tnear = DIST ? __uint_as_float((unsigned)*dist_at(sp) << 16) : 0.f;
+            return lds[sp * BLOCK];
+        }
+        tnear = 0.f;
+        return *ovf_at(sp);
     }
     __device__ __forceinline__ unsigned load(int at) const
     {
@@ -657,9 +691,9 @@ __device__ __forceinline__ bool qwide_step(const float4 a0, const float4 a1, con
         if (k0 == kMissKey) return true;
         cur = child_ref(base4, meta, k0 & 3u);
         const int m = (k1 != kMissKey ? 1 : 0) + (k2 != kMissKey ? 1 : 0) + (k3 != kMissKey ? 1 : 0);
-        if (m == 3) st.store(st.sp, child_ref(base4, meta, k3 & 3u));
-        if (m >= 2) st.store(st.sp + m - 2, child_ref(base4, meta, k2 & 3u));
-        if (m >= 1) st.store(st.sp + m - 1, child_ref(base4, meta, k1 & 3u));
+        if (m == 3) st.store_keyed(st.sp, child_ref(base4, meta, k3 & 3u), k3);
+        if (m >= 2) st.store_keyed(st.sp + m - 2, child_ref(base4, meta, k2 & 3u), k2);
+        if (m >= 1) st.store_keyed(st.sp + m - 1, child_ref(base4, meta, k1 & 3u), k1);
         st.sp += m;
         return false;
     } else {
@@ -676,6 +710,26 @@ __device__ __forceinline__ bool qwide_step(const float4 a0, const float4 a1, con
         cur = next;
         return false;
     }
+}
+
+// Next deferred item of a closest-hit walk on the wide tree (kDone when the stack is empty).  With
+// entry distances on the stack, up to two entries that start at or beyond the current far distance
+// are dropped on the way: a third candidate is taken as it is (its box test will reject it), so the
+// number of dependent LDS reads per iteration stays bounded.
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ unsigned pop_next(STACK &st, float far_t)
+{
+    if (ANYHIT || !STACK::kDist) return st.sp ? st.pop() : kDone;
+    unsigned cur = kDone;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (cur == kDone && st.sp) {
+            float tn;
+            const unsigned c = st.pop_keyed(tn);
+            if (k == 2 || !(tn >= far_t)) cur = c;
+        }
+    }
+    return cur;
 }
 
 // Stepwise traversal of the quantized 4-wide tree: an iteration handles one
@@ -730,7 +784,7 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
             }
             need_pop = !(leaf & 3u) && (cur != kDone);
         }
-        if (need_pop) cur = st.sp ? st.pop() : kDone;
+        if (need_pop) cur = pop_next<ANYHIT>(st, r.far_t);
         if ((unsigned)__popcll(__ballot(true)) < min_active) break;
     }
     s.cur = cur;
@@ -820,7 +874,7 @@ __device__ __forceinline__ void traverse_wide_split(const SceneDev &sc, LaneStat
             leaf = cur;
             need_pop = true;
         }
-        if (need_pop) cur = st.sp ? st.pop() : kDone;
+        if (need_pop) cur = pop_next<ANYHIT>(st, r.far_t);
         if ((unsigned)__popcll(__ballot(true)) < min_active) break;
     }
     s.cur = cur;
@@ -855,7 +909,7 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
                 const float4 a2 = q[2];
                 pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray_lean(s), r.near_t, r.far_t, st, cur);
             }
-            if (pop) cur = st.sp ? st.pop() : kDone;
+            if (pop) cur = pop_next<ANYHIT>(st, r.far_t);
         }
         if (cur != kDone && (cur & 3u)) {
             steps++;
@@ -899,7 +953,7 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
                 s.hit = 1u;
                 cur = kDone;
             } else {
-                cur = st.sp ? st.pop() : kDone;
+                cur = pop_next<ANYHIT>(st, r.far_t);
             }
         }
         if ((unsigned)__popcll(__ballot(true)) < min_active) break;
@@ -917,8 +971,8 @@ struct CoopItem {
     float tnear;
 };
 
-template <bool ANYHIT, class STATE, int BLOCK, int LDS_DEPTH>
-__device__ __forceinline__ void coop_finish_wide(const SceneDev &sc, STATE &s, Stack<BLOCK, LDS_DEPTH> &st,
+template <bool ANYHIT, class STATE, int BLOCK, int LDS_DEPTH, bool DIST>
+__device__ __forceinline__ void coop_finish_wide(const SceneDev &sc, STATE &s, Stack<BLOCK, LDS_DEPTH, DIST> &st,
                                                  unsigned p, CoopItem *work, unsigned cap)
 {
     const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
@@ -1077,8 +1131,8 @@ __device__ __forceinline__ void coop_finish_wide(const SceneDev &sc, STATE &s, S
 // triangle arithmetic on a superset of candidates); on an exact-distance tie
 // the id may be another triangle of the tie, and visit counters of such a ray
 // differ (other visit order, pop-time culling).
-template <bool ANYHIT, bool STATS, int BLOCK, int LDS_DEPTH>
-__device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, Stack<BLOCK, LDS_DEPTH> &st, Counters &cnt,
+template <bool ANYHIT, bool STATS, int BLOCK, int LDS_DEPTH, bool DIST>
+__device__ __forceinline__ void coop_finish(const SceneDev &sc, LaneState &s, Stack<BLOCK, LDS_DEPTH, DIST> &st, Counters &cnt,
                                          unsigned p, CoopItem *work, unsigned cap)
 {
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(sc.nodes);
@@ -1376,47 +1430,56 @@ template <bool ANYHIT, bool STATS, int MODE, class IO>
 struct TraceTune {
     static constexpr int waves = RTC_TRACE_WAVES_PER_SIMD;
     static constexpr int lds_depth = kLdsDepth;
+    static constexpr bool stack_dist = false; // entry distances beside the LDS stack entries (closest-hit, wide tree)
 };
 #if RTC_TRACE_TUNED
 template <bool ANYHIT, class IO> // exact forms without visit counters
 struct TraceTune<ANYHIT, false, 0, IO> {
     static constexpr int waves = RTC_TUNE_EXACT_WAVES;
     static constexpr int lds_depth = kLdsDepth;
+    static constexpr bool stack_dist = false;
 };
 template <bool ANYHIT, class IO>
 struct TraceTune<ANYHIT, false, 1, IO> {
     static constexpr int waves = RTC_TUNE_EXACT_WAVES;
     static constexpr int lds_depth = kLdsDepth;
+    static constexpr bool stack_dist = false;
 };
 template <>
 struct TraceTune<false, false, 3, PrimaryIO> {
     static constexpr int waves = RTC_TUNE_PRIMARY_WAVES;
     static constexpr int lds_depth = RTC_TUNE_PRIMARY_LDS;
+    static constexpr bool stack_dist = RTC_TUNE_PRIMARY_DIST != 0;
 };
 template <>
 struct TraceTune<true, false, 3, QueueIO> {
     static constexpr int waves = RTC_TUNE_ANY3_WAVES;
     static constexpr int lds_depth = RTC_TUNE_ANY3_LDS;
+    static constexpr bool stack_dist = false;
 };
 template <>
 struct TraceTune<true, false, 2, QueueIO> {
     static constexpr int waves = RTC_TUNE_ANY2_WAVES;
     static constexpr int lds_depth = RTC_TUNE_ANY2_LDS;
+    static constexpr bool stack_dist = false;
 };
 template <>
 struct TraceTune<false, false, 2, QueueIO> {
     static constexpr int waves = RTC_TUNE_EXT2_WAVES;
     static constexpr int lds_depth = RTC_TUNE_EXT2_LDS;
+    static constexpr bool stack_dist = RTC_TUNE_EXT2_DIST != 0;
 };
 template <>
 struct TraceTune<false, false, 6, QueueIO> {
     static constexpr int waves = RTC_TUNE_EXT6_WAVES;
     static constexpr int lds_depth = RTC_TUNE_EXT6_LDS;
+    static constexpr bool stack_dist = false;
 };
 template <>
 struct TraceTune<true, false, 6, QueueIO> {
     static constexpr int waves = RTC_TUNE_ANY6_WAVES;
     static constexpr int lds_depth = RTC_TUNE_ANY6_LDS;
+    static constexpr bool stack_dist = false;
 };
 #endif
 
@@ -1426,11 +1489,12 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
 {
     constexpr int kDepth = TraceTune<ANYHIT, STATS, MODE, IO>::lds_depth;
     constexpr bool kWide = MODE == 2 || MODE == 3 || MODE == 6; // forms on the quantized 4-wide tree
-    __shared__ unsigned lds_stack[kDepth * kBlock];
+    constexpr bool kDist = TraceTune<ANYHIT, STATS, MODE, IO>::stack_dist && kWide && !ANYHIT;
+    __shared__ unsigned lds_stack[Stack<kBlock, kDepth, kDist>::kLdsWords * kBlock];
     __shared__ unsigned lds_index[kBlock]; // queue position of the lane's ray: needed again only when it retires
     const unsigned n = n_ptr ? *n_ptr : n_val;
     const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
-    Stack<kBlock, kDepth> st;
+    Stack<kBlock, kDepth, kDist> st;
     st.lds = lds_stack + threadIdx.x;
     st.ovf_base = tl.ovf;
     st.ovf_lane = gtid;
