@@ -141,6 +141,34 @@ def test_cli_frame_is_the_library_frame(rt, scenes, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_exact_frame_against_the_oracle(O, scenes, tmp_path):
+    """OBJ file -> rtcli --exact -> image, against the oracle's render of the mesh the file was written
+    from: the whole command-line path (loader, scene set-up, exact traversal, resolve) checked by the CPU
+    restatement and not only by the library.  The accumulators agree to rtol 2e-5 (order of the f32
+    additions), so an 8-bit channel may differ by one level where the value sits on a rounding boundary."""
+    sc = scenes.load("test-mesh", n_tris=3000, seed=11)
+    path = str(tmp_path / "scene.obj")
+    scenes.write_obj(sc, path)
+    W, H, spp, b = 96, 54, 4, 2
+    cam, light = sc.camera, sc.light
+    ppm = str(tmp_path / "exact.ppm")
+    out = run("--scene", path, "-n", str(spp), "-b", str(b), "--width", str(W), "--height", str(H), "--exact",
+              "--eye", "%r,%r,%r" % tuple(float(x) for x in cam.eye),
+              "--target", "%r,%r,%r" % tuple(float(x) for x in cam.target),
+              "--up", "%r,%r,%r" % tuple(float(x) for x in cam.up), "--fov", repr(float(cam.fov_deg)),
+              "--light-pos", "%r,%r,%r" % tuple(float(x) for x in light.pos),
+              "--light-power", repr(float(light.intensity[0])), "--output", ppm)
+    assert out.returncode == 0, out.stderr + out.stdout
+    So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
+    ao, sto = So.render(cam, light, W, H, spp, max_bounces=b)
+    assert ("total_rays: %d," % sto["total_rays"]) in out.stdout
+    want = O.resolve(ao).astype(np.int16)
+    got = read_ppm(ppm).astype(np.int16)
+    diff = np.abs(got - want)
+    assert diff.max() <= 1 and (diff != 0).mean() < 5e-3, (diff.max(), (diff != 0).mean())
+
+
+@pytest.mark.gpu
 def test_cli_checkpoint_resume_gives_the_uninterrupted_frame(scenes, tmp_path):
     sc = scenes.load("cornell-class")
     path = str(tmp_path / "scene.obj")
