@@ -162,3 +162,22 @@ def test_queue_order_does_not_change_the_image(rt, ctx, scenes):
         assert np.array_equal(a, a0), name
         assert s["total_rays"] == s0["total_rays"], name
     Sg.close()
+
+
+@pytest.mark.parametrize("which", ["exact", "default"])
+def test_refill_threshold_does_not_change_the_image(rt, ctx, ctx_default, scenes, which):
+    """How many lanes of a wave may idle before it fetches new rays decides which lane walks which ray
+    and nothing else: the accumulator and the ray counts are the same bit for bit for any threshold, in
+    the exact forms and in the library's default forms."""
+    c = ctx if which == "exact" else ctx_default
+    sc = scenes.load("test-mesh", n_tris=4000, seed=9)
+    Sg = rt.Scene(c, sc.positions, sc.indices, sc.geom_normals)
+    out = []
+    for deep, depth0 in ((40, 20), (1, 1), (64, 64), (17, 53)):
+        c.set_option("min_active", deep)
+        c.set_option("min_active_depth0", depth0)
+        out.append(Sg.render(sc.camera, sc.light, 160, 90, 4, max_bounces=3))
+    for a, s in out[1:]:
+        assert np.array_equal(a, out[0][0])
+        assert s["total_rays"] == out[0][1]["total_rays"]
+    Sg.close()
