@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--shard", default="tile", choices=["sample", "tile"],
                     help="tile: the frame's tiles are dealt round-robin to the ranks (strong scaling, default); "
                          "sample: every rank renders --spp samples of the whole frame per step (weak scaling)")
-    ap.add_argument("--max-paths", type=int, default=None, help="path slots per render pass (library default 2^26)")
+    ap.add_argument("--max-paths", type=int, default=None, help="path slots per render pass (library default 2^28)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other workloads and the exact-mode rates")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="timed seconds per extra measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")

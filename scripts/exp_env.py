@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Runs bench.py once per environment setting and prints the per-kernel milliseconds side by side.
-usage: exp_env.py [--workload W] [--steps N] [--lib PATH] NAME=VALUE[,NAME=VALUE..] ...   ("base" = no change)"""
+usage: exp_env.py [--workload W] [--steps N] [--lib PATH] NAME=VALUE[,NAME=VALUE..] ...   ("base" = no change;
+"wl=W" switches the workload for the settings after it; "args=--flag,value,..." gives bench.py extra arguments)"""
 import json, os, subprocess, sys
 args = sys.argv[1:]
 wl, steps, spp = "san-miguel-class", "3", "32"
@@ -16,12 +17,16 @@ for setting in args:
         wl = setting[3:]
         continue
     env = dict(os.environ)
-    if setting != "base":
+    extra = []
+    if setting.startswith("args="):
+        extra = setting[5:].split(",")
+    elif setting != "base":
         for kv in setting.split(","):
             k, v = kv.split("=", 1)
             env[k] = v
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", steps, "--warmup", "1", "--workload", wl,
-                        "--spp", spp, "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--spp", spp, "--no-extras", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True,
+                       timeout=600)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(setting, "FAILED", p.stderr[-500:])

@@ -258,3 +258,22 @@ def test_deep_stack_fast_forms(O, rt, ctx_default, coop):
         og, _ = Sg.occluded_stream(rays, stats=False)
         assert np.array_equal(og, oo), form
     Sg.close()
+
+
+def test_pass_size_at_full_size(rt, ctx_default, scenes):
+    """The 1920x1080 frame at the reference's 128 samples per pixel as one pass of 2.65e8 paths (the
+    library default) and as sixteen passes of 2^24: same ray totals, accumulators equal up to the order of
+    the per-pixel f32 additions.  (Slot indices, queue offsets and sort sizes beyond 2^26 entries.)"""
+    sc = scenes.load("sponza-class")
+    W, H, spp, b = 1920, 1080, 128, 1
+    Sg = rt.Scene(ctx_default, sc.positions, sc.indices, sc.geom_normals)
+    try:
+        one, s1 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+        ctx_default.set_max_paths(1 << 24)
+        many, s2 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+    finally:
+        ctx_default.set_max_paths(1 << 28)
+        Sg.close()
+    assert (one[..., 3] == spp).all() and np.isfinite(one).all()
+    assert s1["total_rays"] == s2["total_rays"]
+    assert np.allclose(one, many, rtol=2e-5, atol=1e-6)

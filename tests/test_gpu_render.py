@@ -74,7 +74,7 @@ def test_sharding_and_passes(rt, ctx, scenes):
     # a workspace smaller than the frame forces tile chunking
     ctx.set_max_paths(4096)
     small, s2 = Sg.render(sc.camera, sc.light, W, H, spp)
-    ctx.set_max_paths(1 << 24)
+    ctx.set_max_paths(1 << 28)  # the library default
     assert np.allclose(small, full, rtol=RTOL, atol=ATOL) and s2["total_rays"] == st["total_rays"]
     Sg.close()
 
