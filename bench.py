@@ -462,17 +462,17 @@ def extras(rt, scenes, ctx, args, sc_main, scene_main, bounces_main, value_main,
 
     name = "%s b=%d" % (args.workload, bounces_main)
     out[name] = {"value": round(value_main, 2), "unit": "Mrays/s", "note": "the line's value",
-                 "exact_mode": exact_rate(scene_main, sc_main, 32, bounces_main)}
+                 "exact_mode": exact_rate(scene_main, sc_main, args.spp, bounces_main)}
     scene_main.close()
     for wl in sorted(WORKLOADS):
         if wl == args.workload:
             continue
         b = WORKLOADS[wl]["bounces"]
         sc, scene, build_s = load(wl)
-        rec = timed_rate(torch, scene, sc, acc, W, H, 32, b, stream, args.min_seconds)
+        rec = timed_rate(torch, scene, sc, acc, W, H, args.spp, b, stream, args.min_seconds)
         rec["triangles"] = sc.num_triangles
         rec["bvh_build_s"] = round(build_s, 3)
-        rec["exact_mode"] = exact_rate(scene, sc, 32, b)
+        rec["exact_mode"] = exact_rate(scene, sc, args.spp, b)
         out["%s b=%d" % (wl, b)] = rec
         scene.close()
     return out
