@@ -733,15 +733,16 @@ __device__ __forceinline__ unsigned pop_next(STACK &st, float far_t)
 }
 
 // Stepwise traversal of the quantized 4-wide tree: an iteration handles one
-// wide node (four child boxes, 64 bytes) or one triangle, and the first three
-// 16-byte loads are shared by both kinds of item, so an iteration costs four
-// vector memory instructions whatever the lanes are doing -- and a wide node
-// stands for about 2.2 binary nodes.  The trace kernels are bound by the vector
-// memory front end (address unit and L1 tag rate), not by arithmetic, which is
-// why trading bytes for decode arithmetic pays.
+// item -- a wide node (four child boxes) or one triangle, 48 bytes either way --
+// and its three 16-byte loads are the same instructions for both kinds, so an
+// iteration costs three vector memory instructions whatever the lanes are
+// doing, and a wide node stands for about 2.2 binary nodes.  The trace kernels
+// are bound by the CU's vector memory path (L1 line lookups, misses in flight)
+// as much as by arithmetic, which is why trading bytes for decode arithmetic
+// pays.
 //
-// Child planes are decoded in ray space: t = byte * (scale/d) + (origin - o)/d.
-// The boxes are conservative (see DevQWideNode), the hit children are visited
+// Child planes are decoded in ray space: t = byte * (step/d) + (origin - o)/d.
+// The boxes are conservative (see DevQNode), the hit children are visited
 // nearest first (ties in slot order = left to right) and the others deferred
 // nearest on top.  The triangle arithmetic is that of the binary forms, so hit
 // distances agree with them except where the visit order matters to rounding
