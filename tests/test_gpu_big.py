@@ -161,6 +161,24 @@ def test_big_full_size_defaults_against_exact(rt, big):
     assert np.array_equal(acc, af) and rays == stf["total_rays"]
 
 
+def test_big_full_size_exact_against_oracle(big):
+    """The full 1920x1080 frame, max_bounces 2, one sample per pixel: the exact configuration on the GPU
+    against the oracle's default integrator (all 2 M paths, not a reduced frame), accumulator and the
+    per-ray counters; the library defaults against the same oracle frame under the fast-mode rules."""
+    sc = big.sc
+    W, H, spp, b = 1920, 1080, 1, 2
+    ao, sto = big.So.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+    ae, ste = big.Se.render(sc.camera, sc.light, W, H, spp, max_bounces=b, visit_stats=True)
+    assert np.array_equal(ae[..., 3], ao[..., 3])
+    assert np.allclose(ae, ao, rtol=RTOL, atol=ATOL), float(np.abs(ae - ao).max())
+    for k in COUNTERS:
+        assert ste[k] == sto[k], (k, ste[k], sto[k])
+    af, stf = big.Sf.render(sc.camera, sc.light, W, H, spp, max_bounces=b)
+    assert abs(stf["total_rays"] - sto["total_rays"]) <= 1e-3 * sto["total_rays"]
+    differs = ~np.isclose(af, ao, rtol=RTOL, atol=ATOL).all(axis=-1)
+    assert differs.mean() < 5e-3, differs.mean()
+
+
 def test_big_4k_progressive_sample_ranges(rt, big):
     """3840x2160, progressive: a frame rendered as successive sample ranges (what sample-range
     sharding reduces) equals the frame rendered at once up to the order of the f32 pixel sums, every
