@@ -191,8 +191,8 @@ void rt_ctx_destroy(rt_ctx *ctx);
 int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value);
 
 /* Upper bound of paths per render pass, 4096..2^30 (default 2^28: a 1920x1080 frame at 128 samples
- * per pixel in one pass; the workspace, about 212 bytes per path, is sized lazily from what a
- * call needs, so only frames that large take the 57 GB that go with it). */
+ * per pixel in one pass; the workspace, about 180 bytes per path, is sized lazily from what a
+ * call needs, so only frames that large take the 48 GB that go with it). */
 int rt_ctx_set_max_paths(rt_ctx *ctx, uint64_t max_paths);
 
 /* Bvh::build, src/bvh/build.rs:45-63 (binned SAH, 8 buckets, leaf <= 8) on the

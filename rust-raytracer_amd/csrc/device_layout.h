@@ -107,17 +107,15 @@ struct alignas(16) QRay {
 };
 static_assert(sizeof(QRay) == 32, "QRay must be 32 bytes");
 
-// PathInfo of src/integrators/common.rs:14-19 plus the keys of the
-// counter-based random numbers and the slot that owns the path's radiance.
+// PathInfo of src/integrators/common.rs:14-19: the path's weight and the slot that owns its
+// radiance.  The reference also carries the pixel; here pixel and sample index (the keys of the
+// counter-based random numbers) follow from the slot and the pass, and the bounce count is the
+// depth of the launch, so the queue entry is 16 bytes.
 struct alignas(16) PathInfo {
     float w[3];
-    uint32_t slot;   // index into the pass's radiance arrays
-    uint32_t pixel;  // global pixel index  y*width + x
-    uint32_t sample; // global sample index
-    uint32_t bounces;
-    uint32_t pad;
+    uint32_t slot; // index into the pass's radiance arrays: sample * pixel slots + pixel slot
 };
-static_assert(sizeof(PathInfo) == 32, "PathInfo must be 32 bytes");
+static_assert(sizeof(PathInfo) == 16, "PathInfo must be 16 bytes");
 
 struct alignas(16) ShadowInfo {
     float w[3]; // path weight * light weight

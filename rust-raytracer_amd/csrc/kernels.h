@@ -178,6 +178,7 @@ struct ShadeArgs {
     // depth 0 without queues (primary != 0): ray and PathInfo of entry i are rebuilt from pass slot
     // i, its hit distance is hit_t[i], and the entry count is n_in_val (n_in null)
     unsigned primary;
+    unsigned depth; // bounces the paths of this queue have behind them
     unsigned n_in_val;
     const float *hit_t;
     CameraDev cam;

@@ -2009,11 +2009,21 @@ __device__ __forceinline__ bool primary_path(const CameraDev &cam, const PassDev
     pi.w[0] = pi.w[1] = pi.w[2] = 1.f;
     // radiance index: sample-major over the pass's pixel slots (see accumulate_kernel)
     pi.slot = sidx * ps.pixel_slots + p;
-    pi.pixel = pixel;
-    pi.sample = gs;
-    pi.bounces = 0;
-    pi.pad = 0;
     return true;
+}
+
+// Pixel (y * width + x) and global sample index of the path that owns radiance slot `slot`: the
+// inverse of the slot numbering above, for the random-number keys of the deeper bounces.
+__device__ __forceinline__ void path_keys(const PassDev &ps, unsigned slot, unsigned &pixel, unsigned &gs)
+{
+    const unsigned sidx = slot / ps.pixel_slots, p = slot - sidx * ps.pixel_slots;
+    unsigned tl, pin, py, px;
+    divmod(p, ps.tile_size * ps.tile_size, ps.ts2_shift, tl, pin);
+    const unsigned tile = ps.shard_index + (ps.tile_begin + tl) * ps.shard_count;
+    const unsigned ty = tile / ps.tiles_x, tx = tile - ty * ps.tiles_x;
+    divmod(pin, ps.tile_size, ps.ts_shift, py, px);
+    pixel = (ty * ps.tile_size + py) * ps.width + (tx * ps.tile_size + px);
+    gs = ps.sample_base + sidx;
 }
 
 __global__ __launch_bounds__(kGenBlock) void generate_kernel(CameraDev cam, PassDev ps, QRay *rays,
@@ -2151,10 +2161,12 @@ __device__ __forceinline__ void shade_one(const ShadeArgs &a, unsigned i, unsign
     }
 
     // sample_diffuse_ray, src/integrators/common.rs:64-78 + src/brdf.rs:10-17,36-44
-    if (info.bounces < a.max_bounces) {
-        const unsigned key = rng_key(a.seed_key, info.pixel, info.sample);
-        const float u0 = rng_f32(key, 2u + 2u * info.bounces);
-        const float u1 = rng_f32(key, 3u + 2u * info.bounces);
+    if (a.depth < a.max_bounces) {
+        unsigned pixel, gs;
+        path_keys(a.ps, info.slot, pixel, gs);
+        const unsigned key = rng_key(a.seed_key, pixel, gs);
+        const float u0 = rng_f32(key, 2u + 2u * a.depth);
+        const float u1 = rng_f32(key, 3u + 2u * a.depth);
         const Quat q = rotation_to_z(nrm);
         const V3 wo_l = rotate(q, wo);
         const float aa = sqrtf(u0);
@@ -2174,9 +2186,8 @@ __device__ __forceinline__ void shade_one(const ShadeArgs &a, unsigned i, unsign
         o.bn_ray.near_t = 1e-5f;
         o.bn_ray.d[0] = wi.x; o.bn_ray.d[1] = wi.y; o.bn_ray.d[2] = wi.z;
         o.bn_ray.far_t = __builtin_inff();
-        o.bn_info = info;
         o.bn_info.w[0] = pw.x * w; o.bn_info.w[1] = pw.y * w; o.bn_info.w[2] = pw.z * w;
-        o.bn_info.bounces = info.bounces + 1;
+        o.bn_info.slot = info.slot;
     }
 }
 

@@ -142,7 +142,7 @@ struct rt_ctx {
     uint64_t est_key[3] = {0, 0, 0};  // plan the estimate belongs to: scene, slots, depths
     uint64_t pending_key[3] = {0, 0, 0};
     // Paths per render pass.  2^28 holds a 1920x1080 frame at the reference's default 128 samples per pixel
-    // in one pass (57 GB of workspace on a 288 GB GPU); the persistent trace launches pay their ramp and tail
+    // in one pass (48 GB of workspace on a 288 GB GPU); the persistent trace launches pay their ramp and tail
     // once per launch, so one pass of 2^28 paths is 5-8 % faster than four of 2^26.
     uint64_t max_paths = 1ull << 28;
     DevBuf io_a, io_b; // staging for the host-buffer entry points
@@ -1493,13 +1493,14 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 a.infos_in = (const PathInfo *)w.infos[cur].p;
                 a.hit_ids = (const uint32_t *)w.hit_ids.p;
                 a.n_in = n_ray(b);
+                a.depth = b;
+                a.ps = ps; // the pass geometry: pixel and sample of a path follow from its slot
                 if (fused && b == 0) {
                     a.primary = 1;
                     a.n_in = nullptr;
                     a.n_in_val = ps.num_slots;
                     a.hit_t = (const float *)w.hit_t.p;
                     a.cam = cam;
-                    a.ps = ps;
                 }
                 a.normals = sc->dev.normals;
                 a.rays_out = (QRay *)w.rays[cur ^ 1].p;
