@@ -73,6 +73,13 @@
 #ifndef RTC_TUNE_ANY6_LDS
 #define RTC_TUNE_ANY6_LDS 16
 #endif
+// While-while form on the wide tree: the node loop ends when fewer lanes than this are still at a
+// node, instead of running until the last lane has reached its leaf while the others wait there.
+// Measured on one GPU (depth-0 extend launch, 1 = the plain form): San-Miguel-class 39.2 ms -> 37.0 at 8,
+// 36.4 at 24, 35.6 at 40, 35.4 at 48; dragon-class 16.4 -> 15.4; Sponza-class unchanged.
+#ifndef RTC_WW_NODE_MIN
+#define RTC_WW_NODE_MIN 40
+#endif
 // Fewest LDS stack entries any trace kernel keeps per lane: the global overflow area holds the
 // entries beyond that, so it is sized from this value.
 #define RTC_MIN2_(a, b) ((a) < (b) ? (a) : (b))

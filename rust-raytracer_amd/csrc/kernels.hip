@@ -911,6 +911,8 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
                 pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray_lean(s), r.near_t, r.far_t, st, cur);
             }
             if (pop) cur = pop_next<ANYHIT>(st, r.far_t);
+            // the last few lanes still descending do not hold up the lanes that wait at their leaves
+            if (RTC_WW_NODE_MIN > 1 && (unsigned)__popcll(__ballot(!(cur & 3u))) < (unsigned)RTC_WW_NODE_MIN) break;
         }
         if (cur != kDone && (cur & 3u)) {
             steps++;
