@@ -307,6 +307,35 @@ __device__ __forceinline__ void lane_begin(LaneState &s, unsigned root_ref, cons
     s.have_ray = true;
 }
 
+// v_max/v_min as single instructions: fmaxf/fminf on values the compiler cannot
+// prove quiet are preceded by a canonicalising v_max x,x each.  The hardware
+// instructions return the other operand when one is NaN, which is the rule the
+// slab tests rely on.
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // Runs the lane's ray until it is done (s.cur == kDone) or until fewer than
 // `min_active` lanes of the wave are still traversing (the wave then goes back
 // to fetch rays for its idle lanes).
@@ -349,10 +378,10 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
             const float tfyl = __fmaf_rn(fyl, r.rd.y, -s.ordy), tfyr = __fmaf_rn(fyr, r.rd.y, -s.ordy);
             const float tnzl = __fmaf_rn(nzl, r.rd.z, -s.ordz), tnzr = __fmaf_rn(nzr, r.rd.z, -s.ordz);
             const float tfzl = __fmaf_rn(fzl, r.rd.z, -s.ordz), tfzr = __fmaf_rn(fzr, r.rd.z, -s.ordz);
-            const float nearl = fmaxf(fmaxf(fmaxf(tnxl, tnyl), tnzl), r.near_t);
-            const float nearr = fmaxf(fmaxf(fmaxf(tnxr, tnyr), tnzr), r.near_t);
-            const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), r.far_t);
-            const float farr = fminf(fminf(fminf(tfxr, tfyr), tfzr), r.far_t);
+            const float nearl = vmax3(tnxl, tnyl, vmax(tnzl, r.near_t));
+            const float nearr = vmax3(tnxr, tnyr, vmax(tnzr, r.near_t));
+            const float farl = vmin3(tfxl, tfyl, vmin(tfzl, r.far_t));
+            const float farr = vmin3(tfxr, tfyr, vmin(tfzr, r.far_t));
             const bool hl = nearl <= farl;
             const bool hr = nearr <= farr;
             const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
@@ -490,11 +519,11 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
             const float tfyl = __fmaf_rn(fyl, r.rd.y, -s.ordy), tfyr = __fmaf_rn(fyr, r.rd.y, -s.ordy);
             const float tnzl = __fmaf_rn(nzl, r.rd.z, -s.ordz), tnzr = __fmaf_rn(nzr, r.rd.z, -s.ordz);
             const float tfzl = __fmaf_rn(fzl, r.rd.z, -s.ordz), tfzr = __fmaf_rn(fzr, r.rd.z, -s.ordz);
-            const float nearl = fmaxf(fmaxf(fmaxf(tnxl, tnyl), tnzl), r.near_t);
-            const float nearr = fmaxf(fmaxf(fmaxf(tnxr, tnyr), tnzr), r.near_t);
+            const float nearl = vmax3(tnxl, tnyl, vmax(tnzl, r.near_t));
+            const float nearr = vmax3(tnxr, tnyr, vmax(tnzr, r.near_t));
             const float cull_far = SINGLE ? s.far0 : r.far_t;
-            const float farl = fminf(fminf(fminf(tfxl, tfyl), tfzl), cull_far);
-            const float farr = fminf(fminf(fminf(tfxr, tfyr), tfzr), cull_far);
+            const float farl = vmin3(tfxl, tfyl, vmin(tfzl, cull_far));
+            const float farr = vmin3(tfxr, tfyr, vmin(tfzr, cull_far));
             const bool hl = nearl <= farl;
             const bool hr = nearr <= farr;
             const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
@@ -536,35 +565,6 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
     s.tri = tri;
     s.tri_end = tri_end;
     s.steps = steps;
-}
-
-// v_max/v_min as single instructions: fmaxf/fminf on values the compiler cannot
-// prove quiet are preceded by a canonicalising v_max x,x each.  The hardware
-// instructions return the other operand when one is NaN, which is the rule the
-// slab tests rely on.
-__device__ __forceinline__ float vmax(float a, float b)
-{
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmin(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmax3(float a, float b, float c)
-{
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float vmin3(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
 }
 
 // The three 16-byte loads of one traversal item (a node or a triangle of the wide tree, 48 bytes)
@@ -1438,13 +1438,13 @@ struct TraceTune {
 #if RTC_TRACE_TUNED
 template <bool ANYHIT, class IO> // exact forms without visit counters
 struct TraceTune<ANYHIT, false, 0, IO> {
-    static constexpr int waves = RTC_TUNE_EXACT_WAVES;
+    static constexpr int waves = RTC_TUNE_EXACT0_WAVES;
     static constexpr int lds_depth = kLdsDepth;
     static constexpr bool stack_dist = false;
 };
 template <bool ANYHIT, class IO>
 struct TraceTune<ANYHIT, false, 1, IO> {
-    static constexpr int waves = RTC_TUNE_EXACT_WAVES;
+    static constexpr int waves = RTC_TUNE_EXACT1_WAVES;
     static constexpr int lds_depth = kLdsDepth;
     static constexpr bool stack_dist = false;
 };
