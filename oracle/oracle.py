@@ -72,7 +72,7 @@ def build(force=False):
 
 _lib = None
 
-# flags of the baseline build: SURVEY's CPU-baseline recipe (-O3 -march=native, un-fused)
+# flags of the baseline build: full optimisation for the host it runs on, arithmetic still un-fused
 NATIVE_CFLAGS = ["-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=gnu11", "-pthread"]
 
 
