@@ -1,5 +1,5 @@
 #!/bin/bash
-# The measurement set of one round: TAG=r02_a bash scripts/gpu_profile_round.sh
+# One measurement set: TAG=name bash scripts/gpu_profile_round.sh
 #   1. the default bench line (San-Miguel-class, with the other workloads, exact-mode rates and CPU baseline)
 #   2. per workload: the bench command under rocprofv3 --kernel-trace --stats (per-kernel durations)
 #   3. PMC passes (own runs, no tracing flags) for the workloads in WORKLOADS
