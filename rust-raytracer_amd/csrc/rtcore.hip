@@ -10,7 +10,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <exception>
 #include <limits>
 #include <mutex>
 #include <new>
@@ -639,13 +641,53 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
                          const uint32_t *indices, uint32_t num_triangles, const float *geom_normals)
 {
     int rc = RT_OK;
+    // RTCORE_VERBOSE=1: seconds per preparation phase on stderr
+    const bool verbose = getenv("RTCORE_VERBOSE") && getenv("RTCORE_VERBOSE")[0] == '1';
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "rt_scene_create: %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
     unsigned hw = std::thread::hardware_concurrency();
     unsigned threads = hw ? std::min(hw, 16u) : 4u;
     if (const char *env = getenv("RTCORE_BUILD_THREADS")) {
         int v = atoi(env);
         if (v >= 1 && v <= 256) threads = (unsigned)v;
     }
+    // the wide tree is built over a copy of a tree whose larger leaves are split further
+    unsigned leaf_tris = kWideLeafTris;
+    if (const char *env = getenv("RTCORE_WIDE_LEAF_TRIS")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= (int)kWideLeafTris) leaf_tris = (unsigned)v;
+    }
+    unsigned search_buckets = ctx->fast_tree_buckets;
+    if (const char *env = getenv("RTCORE_FAST_TREE_BUCKETS")) {
+        const int v = atoi(env);
+        if (v == 0 || (v >= 2 && v <= 64)) search_buckets = (unsigned)v;
+    }
+    // The fast forms walk a tree of their own: same builder family, wider search (bvh_build.hpp).  It does
+    // not depend on the reference's tree, so the two are built side by side (both builders run their
+    // upper levels on few threads).
+    HostBvh hs;
+    std::exception_ptr search_error;
+    std::thread search_thread;
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{search_thread};
+    if (search_buckets >= 2)
+        search_thread = std::thread([&] {
+            try {
+                const BuildTuning tune{search_buckets, leaf_tris};
+                build_bvh(positions, num_vertices, indices, num_triangles, threads, hs, &tune);
+            } catch (...) {
+                search_error = std::current_exception();
+            }
+        });
     build_bvh(positions, num_vertices, indices, num_triangles, threads, sc->host);
+    phase("reference tree");
     const HostBvh &hb = sc->host;
     if (hb.stats.max_depth > 1024)
         return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth %u beyond the supported 1024", hb.stats.max_depth);
@@ -654,45 +696,47 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     std::vector<BigLeaf> big;
     std::vector<DevNode> dn;
     const uint32_t root = make_dev_nodes(hb.nodes.data(), hb.nodes.size(), hb.root_ref, hb.root_count, dn, big);
+    // fn(begin, end) over [0, n) on the build threads (plain loops over millions of triangles)
+    auto parallel_ranges = [&](size_t n, auto fn) {
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 65536 + 1));
+        if (T == 1) {
+            fn((size_t)0, n);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; t++) pool.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
+        for (auto &th : pool) th.join();
+    };
     auto make_tris = [&](const std::vector<uint32_t> &order, std::vector<DevTri> &dt) {
         dt.resize(num_triangles);
-        for (uint32_t slot = 0; slot < num_triangles; slot++) {
-            uint32_t t = order[slot];
-            const float *a = positions + 3 * (size_t)indices[3 * (size_t)t + 0];
-            const float *b = positions + 3 * (size_t)indices[3 * (size_t)t + 1];
-            const float *c = positions + 3 * (size_t)indices[3 * (size_t)t + 2];
-            DevTri &d = dt[slot];
-            for (int k = 0; k < 3; k++) { // src/triangle_opt.rs:72-81
-                d.v0[k] = a[k];
-                d.e1[k] = b[k] - a[k];
-                d.e2[k] = c[k] - a[k];
+        parallel_ranges(num_triangles, [&](size_t lo, size_t hi) {
+            for (size_t slot = lo; slot < hi; slot++) {
+                uint32_t t = order[slot];
+                const float *a = positions + 3 * (size_t)indices[3 * (size_t)t + 0];
+                const float *b = positions + 3 * (size_t)indices[3 * (size_t)t + 1];
+                const float *c = positions + 3 * (size_t)indices[3 * (size_t)t + 2];
+                DevTri &d = dt[slot];
+                for (int k = 0; k < 3; k++) { // src/triangle_opt.rs:72-81
+                    d.v0[k] = a[k];
+                    d.e1[k] = b[k] - a[k];
+                    d.e2[k] = c[k] - a[k];
+                }
+                d.id = t;
+                d.pad[0] = d.pad[1] = 0;
             }
-            d.id = t;
-            d.pad[0] = d.pad[1] = 0;
-        }
+        });
     };
     std::vector<DevTri> dt;
     make_tris(hb.order, dt);
-    // the wide tree is built over a copy of the tree whose larger leaves are split further
-    unsigned leaf_tris = kWideLeafTris;
-    if (const char *env = getenv("RTCORE_WIDE_LEAF_TRIS")) {
-        int v = atoi(env);
-        if (v >= 1 && v <= (int)kWideLeafTris) leaf_tris = (unsigned)v;
-    }
+    phase("device nodes + triangles");
     std::vector<DevNode> xdn;
     std::vector<uint32_t> xorder;
     uint32_t xroot = root;
     uint32_t extra_depth = 0, fast_depth = hb.stats.max_depth;
-    unsigned search_buckets = ctx->fast_tree_buckets;
-    if (const char *env = getenv("RTCORE_FAST_TREE_BUCKETS")) {
-        const int v = atoi(env);
-        if (v == 0 || (v >= 2 && v <= 64)) search_buckets = (unsigned)v;
-    }
     if (search_buckets >= 2) {
-        // the fast forms walk a tree of their own: same builder family, wider search (bvh_build.hpp)
-        HostBvh hs;
-        const BuildTuning tune{search_buckets, leaf_tris};
-        build_bvh(positions, num_vertices, indices, num_triangles, threads, hs, &tune);
+        search_thread.join();
+        if (search_error) std::rethrow_exception(search_error);
+        phase("search tree (rest)");
         std::vector<DevNode> sdn;
         std::vector<BigLeaf> sbig;
         const uint32_t sroot = make_dev_nodes(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, sdn, sbig);
@@ -701,15 +745,18 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     } else {
         extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, big, xdn, xroot, xorder);
     }
+    phase("refined leaves");
     std::vector<DevTri> xdt;
     make_tris(xorder, xdt);
     std::vector<float> n4((size_t)num_triangles * 4);
-    for (uint32_t t = 0; t < num_triangles; t++) {
-        n4[4 * (size_t)t + 0] = geom_normals[3 * (size_t)t + 0];
-        n4[4 * (size_t)t + 1] = geom_normals[3 * (size_t)t + 1];
-        n4[4 * (size_t)t + 2] = geom_normals[3 * (size_t)t + 2];
-        n4[4 * (size_t)t + 3] = 0.f;
-    }
+    parallel_ranges(num_triangles, [&](size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; t++) {
+            n4[4 * t + 0] = geom_normals[3 * t + 0];
+            n4[4 * t + 1] = geom_normals[3 * t + 1];
+            n4[4 * t + 2] = geom_normals[3 * t + 2];
+            n4[4 * t + 3] = 0.f;
+        }
+    });
 
     auto upload = [&](DevBuf &buf, const void *src, size_t bytes) -> int {
         int r = buf.ensure(bytes ? bytes : 16);
@@ -718,9 +765,11 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         sc->device_bytes += bytes;
         return RT_OK;
     };
+    phase("wide-order triangles, normals");
     std::vector<DevWideNode> wn;
     uint32_t wide_depth = 0;
     const uint32_t wroot = collapse_wide4(xdn.data(), xdn.size(), xroot, wn, &wide_depth);
+    phase("4-wide collapse");
     sc->num_wide_nodes = (uint32_t)wn.size();
     WideLayout layout;
     unsigned align_mode = 0;
@@ -731,11 +780,13 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         return fail(RT_ERR_LIMIT, "rt_scene_create: %u units in the wide tree, limit is 2^30", layout.num_units);
     std::vector<Unit> items;
     pack_wide4(wn, layout, xdt.data(), num_triangles, items);
+    phase("layout + quantize + pack");
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
     if (rc == RT_OK) rc = upload(sc->witems, items.data(), items.size() * sizeof(Unit));
     if (rc == RT_OK) rc = upload(sc->tris, dt.data(), dt.size() * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
     if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
+    phase("uploads");
     // Deepest traversal stack of a lane.  Binary walk: one deferred sibling per level.
     // Wide walk: up to three deferred children per wide level.
     sc->stack_bound = std::max(std::max(hb.stats.max_depth, fast_depth + extra_depth), 3u * wide_depth) + 1u;
