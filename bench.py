@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other workloads and the exact-mode rates")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="timed seconds per extra measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work of the baseline leg, both rates together")
     args = ap.parse_args()
 
     import numpy as np
@@ -300,7 +300,9 @@ def main():
                                  pmc_file)
         for k, rec in kernels.items():   # the same fractions for every trace kernel, short form
             r = make_roofline(rec, (pmc.get("kernels") or {}).get(rec["kernel"]), pmc_file)
-            rec["hbm_frac"] = r["frac"]
+            rec["bound"] = r["bound"]
+            rec["hbm_frac"] = r["hbm"]["frac"]
+            rec["address_unit_busy_frac"] = r["units"].get("address_unit_busy_frac")
             rec["valu_issue_frac"] = r["units"].get("valu_issue_frac")
             rec["valu_algorithmic_frac"] = r["valu_algorithmic_frac"]
 
@@ -362,18 +364,19 @@ def make_roofline(rec, pmc, pmc_file):
     launch stream); `pmc`: per-launch hardware counters of the same kernel from the committed
     rocprofv3 --pmc passes (None when there is no profile of this build).
 
-    frac is MEASURED HBM bytes per launch / launch time / HBM peak.  The algorithmic bytes (the
-    reference's walk: 64 B per node visit, 48 B per triangle test) are mostly served by L1/L2 and by
-    the 4-wide tree's smaller nodes, so they are reported beside it, not divided by the HBM peak.  The
-    units that do bound the kernel are the vector ALUs' issue slots and the vector-memory address
-    unit: `units` holds their busy fractions."""
+    `bound` names the most-utilised unit the counters show and `frac` is that unit's busy fraction:
+    the vector-memory address unit (TA_TA_BUSY / (256 CUs x kernel cycles)), VALU issue
+    (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles)) or HBM (measured bytes / time / peak).
+    The HBM side is kept under `hbm`: bytes from FETCH_SIZE x the calibrated factor + WRITE_SIZE, the
+    part of them the kernel asked for (L2 misses x 48-byte items), and the reminder that FETCH_SIZE
+    counts Infinity-Cache hits.  The algorithmic bytes (the reference's walk: 64 B per node visit,
+    48 B per triangle test) are mostly served by L1/L2, so they are reported, never divided by a peak."""
     t = rec["avg_launch_ms"] * 1e-3
     alg_bytes = rec["bytes_per_ray"] * rec["rays_per_launch"]
     alg_flops = rec["flops_per_ray"] * rec["rays_per_launch"]
     r = {
-        "bound": "hbm",
-        "kernel": rec["kernel"],
-        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+        "bound": None, "kernel": rec["kernel"],
+        "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
         "traffic_source": pmc_file,
         "avg_launch_ms": rec["avg_launch_ms"], "launches": rec["launches"], "rays_per_launch": rec["rays_per_launch"],
         "algorithmic_bytes_per_launch": round(alg_bytes, 0),
@@ -383,31 +386,60 @@ def make_roofline(rec, pmc, pmc_file):
         "valu_algorithmic_tflops": round(alg_flops / t / 1e12, 2) if t > 0 else None,
         "valu_algorithmic_frac": round(alg_flops / t / 1e12 / VALU_PEAK_TFLOPS, 4) if t > 0 else None,
         "units": {},
+        "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None,
+                "note": "FETCH_SIZE counts Infinity-Cache hits as well: frac is an upper bound on HBM use"},
     }
-    if pmc and t > 0:
-        traffic = pmc.get("hbm_read_bytes_per_launch", 0.0) + pmc.get("hbm_write_bytes_per_launch", 0.0)
-        if traffic > 0:
-            # the profiled launches hold the same rays per launch as the timed ones (same pass size);
-            # scale by the ray counts in case they do not
-            scale = rec["rays_per_launch"] / pmc["rays_per_launch"] if pmc.get("rays_per_launch") else 1.0
-            r["traffic"] = round(traffic * scale, 0)
-            r["achieved"] = round(traffic * scale / t / 1e9, 1)
-            r["frac"] = round(traffic * scale / t / 1e9 / HBM_PEAK_GBS, 4)
-            r["algorithmic_over_traffic"] = round(alg_bytes / (traffic * scale), 2)
-        u = r["units"]
-        if "valu_issue_busy_at_2_cycles" in pmc:
-            # SQ_INSTS_VALU x 2 cycles (a wave64 instruction on a SIMD-32) / (1024 SIMDs x kernel cycles)
-            u["valu_issue_frac"] = round(pmc["valu_issue_busy_at_2_cycles"], 4)
-        if "active_lanes_per_valu_instruction" in pmc:
-            u["valu_lane_frac"] = round(pmc["active_lanes_per_valu_instruction"] / 64.0, 4)
-        if "valu_issue_frac" in u and "valu_lane_frac" in u:
-            u["valu_useful_frac"] = round(u["valu_issue_frac"] * u["valu_lane_frac"], 4)
-        if "vector_memory_address_unit_busy" in pmc:
-            u["address_unit_busy_frac"] = round(pmc["vector_memory_address_unit_busy"], 4)
-        for k in ("l1_hit_rate", "l2_hit_rate", "kernel_cycles", "valu_instructions_per_launch",
-                  "vector_loads_per_launch"):
-            if k in pmc:
-                u[k] = round(pmc[k], 4)
+    if not (pmc and t > 0):
+        r["bound"] = "unknown (no counters of this kernel in profiles/)"
+        return r
+    # the profiled launches hold the same rays per launch as the timed ones (same pass size); scale by
+    # the ray counts in case they do not
+    scale = rec["rays_per_launch"] / pmc["rays_per_launch"] if pmc.get("rays_per_launch") else 1.0
+    h = r["hbm"]
+    traffic = pmc.get("hbm_read_bytes_per_launch", 0.0) + pmc.get("hbm_write_bytes_per_launch", 0.0)
+    if traffic > 0:
+        h["traffic"] = r["traffic"] = round(traffic * scale, 0)
+        h["achieved"] = round(traffic * scale / t / 1e9, 1)
+        h["frac"] = round(traffic * scale / t / 1e9 / HBM_PEAK_GBS, 4)
+        h["fetch_size_factor"] = pmc.get("fetch_size_factor", 2.0)
+        h["fetch_size_factor_source"] = pmc.get("fetch_size_factor_source", "MI355X guide: coalesced 16 B/lane reads")
+        r["algorithmic_over_traffic"] = round(alg_bytes / (traffic * scale), 2)
+        if "l2_misses_per_launch" in pmc:
+            # what the kernel asked the fabric for: one 48-byte item per L2 miss
+            useful = pmc["l2_misses_per_launch"] * 48.0 * scale
+            h["useful_bytes"] = round(useful, 0)
+            h["useful_hbm_frac"] = round(useful / t / 1e9 / HBM_PEAK_GBS, 4)
+    u = r["units"]
+    if "valu_issue_busy_at_2_cycles" in pmc:
+        u["valu_issue_frac"] = round(pmc["valu_issue_busy_at_2_cycles"], 4)
+    if "active_lanes_per_valu_instruction" in pmc:
+        u["valu_lane_frac"] = round(pmc["active_lanes_per_valu_instruction"] / 64.0, 4)
+    if "valu_issue_frac" in u and "valu_lane_frac" in u:
+        u["valu_useful_frac"] = round(u["valu_issue_frac"] * u["valu_lane_frac"], 4)
+    if "vector_memory_address_unit_busy" in pmc:
+        u["address_unit_busy_frac"] = round(pmc["vector_memory_address_unit_busy"], 4)
+    if "address_unit_stalled_by_cache" in pmc:
+        u["address_unit_stalled_by_cache_frac"] = round(pmc["address_unit_stalled_by_cache"], 4)
+    if h["frac"] is not None:
+        u["hbm_frac"] = h["frac"]
+    for k in ("l1_hit_rate", "l2_hit_rate", "kernel_cycles", "valu_instructions_per_launch",
+              "vector_loads_per_launch"):
+        if k in pmc:
+            u[k] = round(pmc[k], 4)
+    # the most-utilised unit bounds the kernel
+    cyc = pmc.get("kernel_cycles", 0.0)
+    cands = []
+    if "address_unit_busy_frac" in u:
+        cands.append((u["address_unit_busy_frac"], "vector-memory address unit (TA busy cycles)",
+                      u["address_unit_busy_frac"] * cyc, cyc, "cycles per CU per launch"))
+    if "valu_issue_frac" in u:
+        cands.append((u["valu_issue_frac"], "VALU issue (2 cycles per wave64 instruction)", u["valu_issue_frac"] * cyc, cyc,
+                      "cycles per SIMD per launch"))
+    if h["frac"] is not None:
+        cands.append((h["frac"], "hbm", h["achieved"], HBM_PEAK_GBS, "GB/s"))
+    if cands:
+        frac, name, achieved, peak, unit = max(cands)
+        r.update(bound=name, frac=round(frac, 4), achieved=round(achieved, 1), peak=round(peak, 1), unit=unit)
     return r
 
 
@@ -463,6 +495,23 @@ def extras(rt, scenes, ctx, args, sc_main, scene_main, bounces_main, value_main,
     name = "%s b=%d" % (args.workload, bounces_main)
     out[name] = {"value": round(value_main, 2), "unit": "Mrays/s", "note": "the line's value",
                  "exact_mode": exact_rate(scene_main, sc_main, args.spp, bounces_main)}
+    if args.workload == "san-miguel-class" and (W, H) == (1920, 1080):
+        # BASELINE config 5: the same scene at 3840x2160, rendered progressively in steps of a sample range
+        # (one step of 32 samples per pixel is as many paths as the 1080p frame at 128)
+        W4, H4, spp4 = 3840, 2160, max(1, args.spp // 4)
+        acc4 = torch.zeros((H4, W4, 4), dtype=torch.float32, device=dev)
+        rec = timed_rate(torch, scene_main, sc_main, acc4, W4, H4, spp4, bounces_main, stream, args.min_seconds)
+        rec["note"] = "3840x2160, progressive: every frame is the next range of %d samples per pixel" % spp4
+        for k, v in EXACT_OPTIONS.items():
+            ctx.set_option(k, v)
+        try:
+            rec["exact_mode"] = timed_rate(torch, scene_main, sc_main, acc4, W4, H4, spp4, bounces_main, stream,
+                                           args.min_seconds)
+        finally:
+            for k, v in DEFAULT_OPTIONS.items():
+                ctx.set_option(k, v)
+        out["%s 4K b=%d" % (args.workload, bounces_main)] = rec
+        del acc4
     scene_main.close()
     for wl in sorted(WORKLOADS):
         if wl == args.workload:
@@ -480,9 +529,11 @@ def extras(rt, scenes, ctx, args, sc_main, scene_main, bounces_main, value_main,
 
 def cpu_baseline(sc, W, H, bounces, budget_s):
     """The CPU oracle (C restatement of the reference's default integrator,
-    integrate_tile_stream_shadow_immediate, tile-parallel like src/main.rs:157-161)
-    timed on this box's host cores on a bounded sample of the same workload, built for this
-    box's CPU with the flags printed in `flags`."""
+    integrate_tile_stream_shadow_immediate, tile-parallel like src/main.rs:157-161) timed on this
+    box's host cores on a bounded sample of the same workload, built for this box's CPU with the
+    flags printed in `flags`.  Two rates: the traversal in the reference's own SSE/AVX2 intrinsics
+    (rt_oracle_simd.c, kind "port-simd": the fairer figure, and the record's value) and the scalar
+    restatement (kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O  # checker / baseline only
     path, flags = O.build_native(tempfile.mkdtemp(prefix="rt_oracle_"))
@@ -492,22 +543,31 @@ def cpu_baseline(sc, W, H, bounces, budget_s):
         flags = "committed build (-O2 -march=x86-64-v3 -ffp-contract=off); native build failed: %s" % flags
     threads = min(os.cpu_count() or 1, 16)
     So = O.Scene(sc.positions, sc.indices, sc.geom_normals)
-    t0 = time.perf_counter()
-    _, st = So.render(sc.camera, sc.light, W, H, 1, max_bounces=bounces, nthreads=threads)
-    dt = time.perf_counter() - t0
-    spp = 1
-    rays, secs = st["total_rays"], dt
-    more = int(min(64, max(0, (budget_s - dt) // max(dt, 1e-3))))
-    if more >= 1:
+
+    def timed(mode, budget):
         t0 = time.perf_counter()
-        _, st = So.render(sc.camera, sc.light, W, H, more, max_bounces=bounces, sample_offset=1, nthreads=threads)
-        secs = time.perf_counter() - t0
-        rays, spp = st["total_rays"], more
-    return {"value": round(rays / 1e6 / secs, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "flags": "gcc " + flags,
-            "sample": "same scene, camera and bounce cap, %dx%d at %d spp (%.1f s of CPU work); scalar C restatement of "
-                      "the reference's default integrator (the Rust binary, AVX2 2- and 4-ray SIMD, cannot be built "
-                      "here)" % (W, H, spp, secs)}
+        _, st = So.render(sc.camera, sc.light, W, H, 1, max_bounces=bounces, nthreads=threads, mode=mode)
+        dt = time.perf_counter() - t0
+        rays, secs, spp = st["total_rays"], dt, 1
+        more = int(min(64, max(0, (budget - dt) // max(dt, 1e-3))))
+        if more >= 1:
+            t0 = time.perf_counter()
+            _, st = So.render(sc.camera, sc.light, W, H, more, max_bounces=bounces, sample_offset=1, nthreads=threads,
+                              mode=mode)
+            secs = time.perf_counter() - t0
+            rays, spp = st["total_rays"], more
+        return rays / 1e6 / secs, spp, secs
+
+    simd_rate, simd_spp, simd_s = timed(O.MODE_STREAM_SHADOW_IMMEDIATE | O.MODE_SIMD, budget_s / 2)
+    scalar_rate, scalar_spp, scalar_s = timed(O.MODE_STREAM_SHADOW_IMMEDIATE, budget_s / 2)
+    return {"value": round(simd_rate, 3), "unit": "Mrays/s", "cores": threads, "kind": "port-simd",
+            "flags": "gcc " + flags + " -mavx2 -mfma",
+            "sample": "same scene, camera and bounce cap, %dx%d at %d spp (%.1f s of CPU work); C restatement of the "
+                      "reference's default integrator with its traversals in the reference's own intrinsics: AVX2 "
+                      "two-rays-by-two-children node filter, four-ray SSE leaf loop, SSE single-ray shadow rays (the Rust "
+                      "binary itself cannot be built here)" % (W, H, simd_spp, simd_s),
+            "scalar": {"value": round(scalar_rate, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                       "sample": "the same frame at %d spp (%.1f s) through the scalar restatement" % (scalar_spp, scalar_s)}}
 
 
 if __name__ == "__main__":

@@ -170,20 +170,28 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       ties, no visit counters, and 1/d is bounded as in the reference's
  *                       packet rays (src/simd_ray.rs:46-47) so that axis-parallel rays are
  *                       culled properly.  Calls that ask for visit counters always run form
- *                       0 or 1.  "traversal_deep" and "traversal_stream" also take two
+ *                       0 or 1.  "traversal_deep" and "traversal_stream" also take three
  *                       experimental variants of form 2 with the same results (kept for
- *                       measurements, neither is faster): 5 = two rays per lane, the loads of
+ *                       measurements, none is faster): 5 = two rays per lane, the loads of
  *                       one issued behind the arithmetic of the other; 6 = a lane walks
  *                       nodes and tests the triangles of the last leaf it reached side by
- *                       side, one node and one triangle per iteration.
+ *                       side, one node and one triangle per iteration; 7 = lanes only walk
+ *                       nodes and the triangles of the leaves they reach go through a job
+ *                       queue of the wave, tested 64 at a time by whichever lanes are free
+ *                       (of triangles at exactly the same distance the lowest id wins).
+ *                       rt_intersect_stream_noalloc runs form 2 where 5 or 7 is selected.
+ *   "traversal_deep_connect" form of the deeper any-hit launches of rt_render alone
+ *                       (same values as "traversal_deep"; -1, the default, follows it)
  *   "fuse_primary"      0/1 (default 1): depth 0 of rt_render without ray and PathInfo queues;
  *                       the extend launch makes the camera rays itself.  Same image bit for
  *                       bit; not used by calls that ask for visit counters.
  *   "fast_tree_buckets" 0 or 2..64 (default 32), read by rt_scene_create: the quantized 4-wide
  *                       tree of forms 2 and 3 is collapsed from a tree of its own, built like the
  *                       reference's (binned SAH) but with that many buckets, every axis tried and
- *                       leaves of at most 3 triangles; 0 collapses it from the reference's tree.
- *                       Forms 0 and 1 always walk the reference's tree.
+ *                       leaves of at most "fast_tree_max_leaf" triangles; 0 collapses it from the
+ *                       reference's tree.  Forms 0 and 1 always walk the reference's tree.
+ *   "fast_tree_max_leaf" 1..3 (default 3), read by rt_scene_create: most triangles in a leaf of
+ *                       the tree of forms 2 and 3
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
  *                       (defaults: never = 0xFFFFFFFF for the bounce rays, 1 for the shadow rays)
  *   "sort_bits"         3..30 key bits that take part in the order
@@ -225,7 +233,7 @@ int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint3
  * largest one only, candidates with an empty side skipped, and leaves of at
  * most max_leaf triangles (1..8; more only where all centroids coincide).
  * Same output conventions as rt_bvh_build_host.  rt_scene_create runs it with
- * (fast_tree_buckets, 3) unless that option is 0. */
+ * (fast_tree_buckets, fast_tree_max_leaf) unless the former is 0. */
 int rt_bvh_build_search_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
                              uint32_t num_triangles, uint32_t threads, uint32_t buckets, uint32_t max_leaf,
                              rt_flat_node *nodes, uint32_t *order, rt_scene_info *info, rt_bvh_stats *stats);

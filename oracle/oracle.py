@@ -61,11 +61,13 @@ class RenderParams(C.Structure):
 MODE_STREAM = 0
 MODE_STREAM_SHADOW_IMMEDIATE = 1
 MODE_SINGLE_RAY = 3
+MODE_SIMD = 0x100  # or-ed into a mode: traversal through the SSE/AVX2 restatement
 
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or (
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "rt_oracle.c"))):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in (
+                "rt_oracle.c", "rt_oracle_simd.c", "rt_oracle.h", "rt_oracle_internal.h"))):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -80,7 +82,8 @@ def build_native(out_dir):
     """Compiles rt_oracle.c for the CPU this runs on (bench.py's cpu_baseline leg: the committed
     library targets x86-64-v3 so that it runs on any box).  Returns (path, flags) or (None, reason)."""
     out = os.path.join(out_dir, "librt_oracle_native.so")
-    cmd = ["gcc"] + NATIVE_CFLAGS + ["-shared", "-o", out, os.path.join(_HERE, "rt_oracle.c"), "-lm", "-lpthread"]
+    cmd = ["gcc"] + NATIVE_CFLAGS + ["-mavx2", "-mfma", "-shared", "-o", out, os.path.join(_HERE, "rt_oracle.c"),
+                                     os.path.join(_HERE, "rt_oracle_simd.c"), "-lm", "-lpthread"]
     try:
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     except (OSError, subprocess.CalledProcessError) as e:
@@ -119,6 +122,9 @@ def lib():
         L.orc_intersect_stream.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(Stats)]
         L.orc_occluded_stream.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(Stats)]
         L.orc_intersect_brute.argtypes = [vp, vp, vp, C.c_uint32]
+        for name in ("orc_simd_intersect1_n", "orc_simd_occluded1_n", "orc_simd_intersect_stream",
+                     "orc_simd_occluded_stream"):
+            getattr(L, name).argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(Stats)]
         L.orc_sample_light.restype = C.c_int
         L.orc_sample_light.argtypes = [vp, vp, vp, C.POINTER(LightC), vp, C.POINTER(C.c_float), vp]
         L.orc_sample_diffuse_ray.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp]
@@ -228,6 +234,21 @@ class Scene:
 
     def occluded_stream(self, rays):
         o, _, st = self._trace(lib().orc_occluded_stream, rays, np.uint8)
+        return o, st
+
+    # the same four traversals through the SSE/AVX2 restatement (rt_oracle_simd.c)
+    def simd_intersect1(self, rays):
+        return self._trace(lib().orc_simd_intersect1_n, rays, np.uint32)
+
+    def simd_occluded1(self, rays):
+        o, _, st = self._trace(lib().orc_simd_occluded1_n, rays, np.uint8)
+        return o, st
+
+    def simd_intersect_stream(self, rays):
+        return self._trace(lib().orc_simd_intersect_stream, rays, np.uint32)
+
+    def simd_occluded_stream(self, rays):
+        o, _, st = self._trace(lib().orc_simd_occluded_stream, rays, np.uint8)
         return o, st
 
     def intersect_brute(self, rays):

@@ -9,90 +9,10 @@
  * tests, where the reference uses fused_mul_sub).
  */
 #define _GNU_SOURCE
-#include "rt_oracle.h"
+#include "rt_oracle_internal.h"
 
-#include <math.h>
 #include <pthread.h>
 #include <stdatomic.h>
-#include <stdlib.h>
-#include <string.h>
-
-#define ORC_NONE 0xFFFFFFFFu
-#define ORC_LEAF_BIT 0x80000000u
-
-/* ------------------------------------------------------------------------ */
-/* small vector helpers.  [3P nalgebra 0.34.1] cross = (ay*bz-az*by,
- * az*bx-ax*bz, ax*by-ay*bx); dot = (ax*bx+ay*by)+az*bz; all un-fused.        */
-
-typedef struct { float x, y, z; } v3;
-
-static inline v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
-static inline v3 v3_load(const float *p) { return v3_make(p[0], p[1], p[2]); }
-static inline void v3_store(float *p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
-static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
-static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
-static inline v3 v3_mul(v3 a, v3 b) { return v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
-static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
-static inline v3 v3_div(v3 a, float s) { return v3_make(a.x / s, a.y / s, a.z / s); }
-static inline v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
-static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-static inline v3 v3_cross(v3 a, v3 b)
-{
-    return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-static inline v3 v3_normalize(v3 a) { return v3_div(a, sqrtf(v3_dot(a, a))); }
-
-/* ------------------------------------------------------------------------ */
-/* src/aabb.rs:11-66                                                         */
-
-typedef struct { v3 min, max; } aabb;
-
-static inline float minf_(float a, float b) { return a < b ? a : b; }
-static inline float maxf_(float a, float b) { return a > b ? a : b; }
-
-static inline aabb aabb_empty(void)
-{
-    aabb b = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
-    return b;
-}
-static inline void aabb_grow(aabb *b, v3 p) /* aabb.rs:50-53 */
-{
-    b->min = v3_make(minf_(b->min.x, p.x), minf_(b->min.y, p.y), minf_(b->min.z, p.z));
-    b->max = v3_make(maxf_(b->max.x, p.x), maxf_(b->max.y, p.y), maxf_(b->max.z, p.z));
-}
-static inline aabb aabb_join(aabb a, aabb o) /* aabb.rs:56-61 */
-{
-    aabb r;
-    r.min = v3_make(minf_(a.min.x, o.min.x), minf_(a.min.y, o.min.y), minf_(a.min.z, o.min.z));
-    r.max = v3_make(maxf_(a.max.x, o.max.x), maxf_(a.max.y, o.max.y), maxf_(a.max.z, o.max.z));
-    return r;
-}
-static inline float aabb_surface_area(aabb b) /* aabb.rs:37-40 */
-{
-    v3 s = v3_sub(b.max, b.min);
-    return 2.f * ((s.x * s.y + s.x * s.z) + s.y * s.z);
-}
-
-/* ------------------------------------------------------------------------ */
-/* src/triangle_opt.rs:19-42  Moeller-Trumbore, un-fused, no back-face cull. */
-
-static inline float tri_intersect(v3 v0, v3 v0v1, v3 v0v2, v3 o, v3 d)
-{
-    v3 pvec = v3_cross(d, v0v1);
-    float det = v3_dot(v0v2, pvec);
-    if (fabsf(det) < 1.1920929e-7f) /* f32::EPSILON */
-        return INFINITY;
-    float inv_det = 1.f / det;
-    v3 tvec = v3_sub(o, v0);
-    float u = v3_dot(tvec, pvec) * inv_det;
-    if (!(u >= 0.f && u <= 1.f))
-        return INFINITY;
-    v3 qvec = v3_cross(tvec, v0v2);
-    float v = v3_dot(d, qvec) * inv_det;
-    if (v < 0.f || u + v > 1.f)
-        return INFINITY;
-    return v3_dot(v0v1, qvec) * inv_det;
-}
 
 float orc_tri_intersect(const float v0[3], const float v0v1[3], const float v0v2[3],
                         const float origin[3], const float direction[3])
@@ -118,32 +38,6 @@ void orc_ray_new(orc_ray *r, const float origin[3], const float direction[3], fl
     r->dir_recip_near[2] = 1.f / direction[2];
     r->dir_recip_near[3] = near_t;
 }
-
-/* ------------------------------------------------------------------------ */
-/* src/bvh.rs:19-34 pointer tree                                             */
-
-typedef struct node {
-    int is_leaf;
-    /* inner: lanes {minL,minR,maxL,maxR} per axis (bvh.rs:21-22) */
-    float bx[4], by[4], bz[4];
-    struct node *child[2];
-    /* leaf: triangles_range */
-    uint32_t first, count;
-} node;
-
-typedef struct { v3 v0v1, v0v2, v0; } tri_opt;
-
-struct orc_scene {
-    uint32_t num_vertices, num_triangles;
-    float *positions;      /* 3*nv */
-    uint32_t *indices;     /* 3*nt */
-    float *geom_normals;   /* 3*nt */
-    tri_opt *triangles;    /* leaf order (bvh.rs:31) */
-    uint32_t *object_indices; /* leaf slot -> mesh triangle (bvh.rs:32) */
-    node *root;
-    uint32_t num_inner;
-    orc_bvh_stats bstats;
-};
 
 typedef struct { v3 centroid; aabb box; } obj_bound;
 
@@ -379,19 +273,6 @@ void orc_scene_flatten(const orc_scene *s, orc_flat_node *nodes, orc_flat_tri *t
 static inline float mm_max(float a, float b) { return a > b ? a : b; }
 static inline float mm_min(float a, float b) { return a < b ? a : b; }
 
-static inline void stats_inner(orc_stats *st, uint64_t rays)
-{
-    st->inner_visit += 1;
-    st->inner_rays += rays;
-}
-static inline void stats_leaf(orc_stats *st, uint64_t rays, uint64_t objs)
-{
-    st->leaf_visit += 1;
-    st->leaf_rays += rays;
-    st->leaf_objs += objs;
-    st->obj_intersect += rays * objs;
-}
-
 /* slab test of src/bvh/intersect1.rs:144-179 (same in occluded1 41-76):
  * near/far box planes picked by the SIGN BIT of 1/d (blendv), t = fmsub(bb,
  * 1/d, o*(1/d)); tnear = max(max(tx,ty), max(tz,near)); tfar likewise.       */
@@ -553,24 +434,6 @@ static inline unsigned slab_stream(const node *n, const orc_ray *ray)
     if (tnear[1] <= tfar[1]) m |= 2u;
     if (tnear[0] <= tnear[1]) m |= 4u;
     return m;
-}
-
-typedef struct { const node *n; uint32_t list; size_t start; } stream_item;
-
-/* scratch lists are sized 32*n entries each like intersect_stream.rs:22-23. */
-typedef struct {
-    uint32_t *buf;
-    size_t cap;
-} stream_scratch;
-
-static uint32_t *scratch_get(stream_scratch *sc, size_t entries)
-{
-    if (sc->cap < entries) {
-        free(sc->buf);
-        sc->buf = (uint32_t *)malloc(entries * sizeof(uint32_t));
-        sc->cap = entries;
-    }
-    return sc->buf;
 }
 
 /* intersect_stream.rs:10-198 + intersect_objs 384-426 */
@@ -993,18 +856,24 @@ static void make_ray(orc_ray *r, v3 o, v3 d, float near_t, float far_t)
     orc_ray_new(r, o3, d3, near_t, far_t);
 }
 
+static const orc_trace_fns scalar_trace_fns = {intersect_stream_impl, occluded_stream_impl, orc_intersect1,
+                                               orc_occluded1};
+
 static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st,
                         stream_scratch *sc)
 {
     const orc_render_params *p = job->p;
     const orc_scene *s = job->s;
+    /* the same integrator over either restatement of the traversal */
+    const orc_trace_fns *fn = (p->mode & ORC_MODE_SIMD) ? &orc_simd_trace_fns : &scalar_trace_fns;
+    const uint32_t mode = p->mode & ~(uint32_t)ORC_MODE_SIMD;
     uint32_t x0 = tx * p->tile_size, y0 = ty * p->tile_size;
     uint32_t tw = p->tile_size < p->width - x0 ? p->tile_size : p->width - x0;   /* main.rs:76-77 */
     uint32_t th = p->tile_size < p->height - y0 ? p->tile_size : p->height - y0;
     size_t max_rays = (size_t)tw * th * p->samples;
     float *tile_px = (float *)calloc((size_t)tw * th * 4, sizeof(float));
 
-    if (p->mode == ORC_MODE_SINGLE_RAY) {
+    if (mode == ORC_MODE_SINGLE_RAY) {
         /* tile_integrator.rs:68-99 + 18-66 */
         for (uint32_t py = 0; py < th; py++)
             for (uint32_t px = 0; px < tw; px++) {
@@ -1021,7 +890,7 @@ static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st
                     uint32_t bounces = 0;
                     v3 weight = v3_make(1.f, 1.f, 1.f);
                     uint32_t hit;
-                    while ((hit = orc_intersect1(s, &ray, st)) != ORC_NONE) {
+                    while ((hit = fn->intersect1(s, &ray, st)) != ORC_NONE) {
                         v3 hp = hit_pos_of(&ray);
                         v3 wo = v3_neg(v3_load(ray.direction));
                         const float *nrm = s->geom_normals + 3 * (size_t)hit;
@@ -1031,7 +900,7 @@ static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st
                         if (orc_sample_light(wo3, nrm, hp3, job->light, wi3, &dist, sw)) {
                             orc_ray sh;
                             make_ray(&sh, hp, v3_load(wi3), SHADOW_RAY_NEAR, dist);
-                            if (!orc_occluded1(s, &sh, st)) {
+                            if (!fn->occluded1(s, &sh, st)) {
                                 v3 c = v3_mul(weight, v3_load(sw));
                                 dst[0] += c.x; dst[1] += c.y; dst[2] += c.z;
                             }
@@ -1054,7 +923,7 @@ static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st
         orc_ray *sh_rays = NULL;
         path_info *sh_infos = NULL;
         uint8_t *sh_occ = NULL;
-        if (p->mode == ORC_MODE_STREAM) {
+        if (mode == ORC_MODE_STREAM) {
             sh_rays = (orc_ray *)malloc(sizeof(orc_ray) * (max_rays ? max_rays : 1));
             sh_infos = (path_info *)malloc(sizeof(path_info) * (max_rays ? max_rays : 1));
             sh_occ = (uint8_t *)malloc(max_rays ? max_rays : 1);
@@ -1081,7 +950,7 @@ static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st
 
         while (n > 0) {
             for (size_t i = 0; i < n; i++) hits[i] = ORC_NONE;
-            intersect_stream_impl(s, rays, hits, (uint32_t)n, st, sc);
+            fn->intersect_stream(s, rays, hits, (uint32_t)n, st, sc);
             size_t new_n = 0, n_sh = 0;
             for (size_t i = 0; i < n; i++) {
                 if (hits[i] == ORC_NONE) continue;
@@ -1094,7 +963,7 @@ static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st
                 v3_store(wo3, wo);
                 v3_store(hp3, hp);
                 if (orc_sample_light(wo3, nrm, hp3, job->light, wi3, &dist, sw)) {
-                    if (p->mode == ORC_MODE_STREAM) {
+                    if (mode == ORC_MODE_STREAM) {
                         make_ray(&sh_rays[n_sh], hp, v3_load(wi3), SHADOW_RAY_NEAR, dist);
                         sh_infos[n_sh] = info;
                         sh_infos[n_sh].weight = v3_mul(info.weight, v3_load(sw));
@@ -1102,7 +971,7 @@ static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st
                     } else {
                         orc_ray sh;
                         make_ray(&sh, hp, v3_load(wi3), SHADOW_RAY_NEAR, dist);
-                        if (!orc_occluded1(s, &sh, st)) {
+                        if (!fn->occluded1(s, &sh, st)) {
                             v3 c = v3_mul(info.weight, v3_load(sw));
                             float *dst = tile_px + 4 * (size_t)info.dest;
                             dst[0] += c.x; dst[1] += c.y; dst[2] += c.z;
@@ -1123,9 +992,9 @@ static void render_tile(render_job *job, uint32_t tx, uint32_t ty, orc_stats *st
                 }
             }
             n = new_n;
-            if (p->mode == ORC_MODE_STREAM && n_sh > 0) {
+            if (mode == ORC_MODE_STREAM && n_sh > 0) {
                 memset(sh_occ, 0, n_sh);
-                occluded_stream_impl(s, sh_rays, sh_occ, (uint32_t)n_sh, st, sc);
+                fn->occluded_stream(s, sh_rays, sh_occ, (uint32_t)n_sh, st, sc);
                 for (size_t i = 0; i < n_sh; i++)
                     if (!sh_occ[i]) {
                         float *dst = tile_px + 4 * (size_t)sh_infos[i].dest;

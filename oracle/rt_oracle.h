@@ -97,7 +97,9 @@ typedef struct orc_light {
 enum {
     ORC_MODE_STREAM = 0,                  /* integrate_stream.rs:56-164  */
     ORC_MODE_STREAM_SHADOW_IMMEDIATE = 1, /* integrate_stream.rs:166-242 */
-    ORC_MODE_SINGLE_RAY = 3               /* tile_integrator.rs:18-99    */
+    ORC_MODE_SINGLE_RAY = 3,              /* tile_integrator.rs:18-99    */
+    /* or-ed into a mode: the traversal calls go to the SSE/AVX2 restatement (rt_oracle_simd.c) */
+    ORC_MODE_SIMD = 0x100
 };
 
 typedef struct orc_render_params {
@@ -147,6 +149,20 @@ void orc_occluded_stream(const orc_scene *s, orc_ray *rays, uint8_t *occluded, u
                          orc_stats *stats);
 /* all-triangles loop in mesh order with the same triangle arithmetic. */
 void orc_intersect_brute(const orc_scene *s, orc_ray *rays, uint32_t *hits, uint32_t n);
+
+/* The same four traversals written with the reference's own intrinsics, instruction for instruction
+ * (rt_oracle_simd.c: SSE + FMA single-ray code of src/bvh/intersect1.rs, AVX2 two-rays-by-two-children
+ * node filter and four-ray leaf loop of src/bvh/intersect_stream.rs).  Second witness for the scalar
+ * restatement above: NaN handling of min/max and the blend lanes come from the hardware here. */
+uint32_t orc_simd_intersect1(const orc_scene *s, orc_ray *ray, orc_stats *stats);
+int orc_simd_occluded1(const orc_scene *s, const orc_ray *ray, orc_stats *stats);
+void orc_simd_intersect1_n(const orc_scene *s, orc_ray *rays, uint32_t *hits, uint32_t n, orc_stats *stats);
+void orc_simd_occluded1_n(const orc_scene *s, const orc_ray *rays, uint8_t *occluded, uint32_t n,
+                          orc_stats *stats);
+void orc_simd_intersect_stream(const orc_scene *s, orc_ray *rays, uint32_t *hits, uint32_t n,
+                               orc_stats *stats);
+void orc_simd_occluded_stream(const orc_scene *s, orc_ray *rays, uint8_t *occluded, uint32_t n,
+                              orc_stats *stats);
 
 /* shading pieces (exposed for known-answer tests) */
 int orc_sample_light(const float dir_out[3], const float normal[3], const float hit_pos[3],

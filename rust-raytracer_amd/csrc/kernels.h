@@ -78,6 +78,18 @@
 #ifndef RTC_TUNE_ANY6_LDS
 #define RTC_TUNE_ANY6_LDS 16
 #endif
+#ifndef RTC_TUNE_EXT7_WAVES
+#define RTC_TUNE_EXT7_WAVES 6
+#endif
+#ifndef RTC_TUNE_EXT7_LDS
+#define RTC_TUNE_EXT7_LDS 19
+#endif
+#ifndef RTC_TUNE_ANY7_WAVES
+#define RTC_TUNE_ANY7_WAVES 7
+#endif
+#ifndef RTC_TUNE_ANY7_LDS
+#define RTC_TUNE_ANY7_LDS 16
+#endif
 // While-while form on the wide tree: the node loop ends when fewer lanes than this are still at a
 // node, instead of running until the last lane has reached its leaf while the others wait there.
 // Measured on one GPU (depth-0 extend launch, 1 = the plain form): San-Miguel-class 39.2 ms -> 37.0 at 8,
@@ -91,7 +103,8 @@
 #if RTC_TRACE_TUNED
 #define RTC_MIN_LDS_STACK_DEPTH \
     RTC_MIN2_(RTC_MIN2_(RTC_MIN2_(RTC_LDS_STACK_DEPTH, RTC_TUNE_EXT2_LDS), RTC_TUNE_PRIMARY_LDS), \
-              RTC_MIN2_(RTC_MIN2_(RTC_TUNE_ANY3_LDS, RTC_TUNE_ANY2_LDS), RTC_MIN2_(RTC_TUNE_EXT6_LDS, RTC_TUNE_ANY6_LDS)))
+              RTC_MIN2_(RTC_MIN2_(RTC_MIN2_(RTC_TUNE_ANY3_LDS, RTC_TUNE_ANY2_LDS), RTC_MIN2_(RTC_TUNE_EXT6_LDS, RTC_TUNE_ANY6_LDS)), \
+                        RTC_MIN2_(RTC_TUNE_EXT7_LDS, RTC_TUNE_ANY7_LDS)))
 #else
 #define RTC_MIN_LDS_STACK_DEPTH RTC_LDS_STACK_DEPTH
 #endif
@@ -125,7 +138,8 @@ struct TraceLaunch {
     unsigned mode;       // 0 = while-while loop, 1 = one item (node or triangle) per iteration,
                          // 2 = one item per iteration on the quantized 4-wide tree, 3 = while-while loop on it
                          // (no visit counters in 2 and 3), 4 = form 1 in the visit order of the reference's
-                         // single-ray closest hit (stream entry points only)
+                         // single-ray closest hit (stream entry points only), 5 = two rays per lane, 6 = node walk
+                         // and triangle tests side by side, 7 = triangle tests through a wave-level job queue
     const unsigned *perm; // optional: process ray perm[i] at position i (queue sorted by key), or null
     unsigned perm_n;      // perm covers (and permutes) queue entries 0..perm_n-1
     // stragglers: a ray that has used coop_steps loop iterations is finished by its
@@ -134,6 +148,7 @@ struct TraceLaunch {
     unsigned coop_cap;
     unsigned coop_steps; // 0xFFFFFFFF = never
     unsigned depth;      // path depth the launch belongs to (slot of the per-depth counters)
+    unsigned job_units_ok; // the wide tree's unit indices fit a triangle job of form 7 (else form 2 runs)
 };
 
 // StreamRay (src/ray.rs:6-12) as three float4.

@@ -792,6 +792,233 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
     s.tri = leaf;
     s.steps = steps;
 }
+// ------------------------------------------------------------------------
+// Stepwise traversal with a wave-level triangle-job queue (form 7, incoherent rays).
+//
+// In traverse_wide_steps() every iteration runs the node code for the lanes that are at a node and
+// the triangle code for the lanes inside a leaf, and with incoherent rays a wave always has both
+// kinds: 28 of 64 lanes are active per instruction.  Here a lane only ever walks nodes.  A leaf it
+// reaches is not tested by that lane: one job per triangle -- owner lane and triangle -- goes
+// into a ring the wave keeps in LDS, and the lane goes straight on with its next deferred node.
+// When 64 jobs are pending the whole wave tests 64 triangles at once, whichever rays they belong
+// to: the lane that runs a job fetches the owner's ray from the owner's registers (ds_bpermute)
+// and merges an accepted distance into the owner's result slot in LDS with one 64-bit minimum on
+// (distance, triangle id).  This is what the reference's stream traversal does on the CPU when it
+// gathers the rays that reached a leaf and tests them four at a time
+// (src/bvh/intersect_stream.rs:384-426), with the wave as the batch.
+//
+// What changes for a ray: between reaching a leaf and the next triangle phase it walks on against
+// a far distance that the pending jobs may still shorten (a few extra visits, as in
+// traverse_wide_split()), and of several triangles at exactly the same distance the one with the
+// lowest id wins whatever the visit order.  Closest distances are those of the other wide forms:
+// every triangle the ordered walk would test is still tested, with the same arithmetic.
+#ifndef RTC_Q_NODE_MIN
+#define RTC_Q_NODE_MIN 24 // with fewer lanes than this at a node, pending jobs and leaves are dealt with first
+#endif
+// 1: a node step and a triangle phase share one wait for memory (their loads are in flight together).
+// Needs 127 VGPRs (4 waves per SIMD) to stay clear of spills: measured 20.2 ms against 22.7 ms for the
+// plain form at 6 waves and 16.7 ms for traverse_wide_steps() on the San-Miguel-class deep extend launch.
+#ifndef RTC_Q_FUSE
+#define RTC_Q_FUSE 0
+#endif
+#ifndef RTC_Q_FUSE_MIN
+#define RTC_Q_FUSE_MIN 24 // pending jobs that are worth a triangle phase beside a node step
+#endif
+#ifndef RTC_Q_LEAF_MIN
+#define RTC_Q_LEAF_MIN 12 // leaves at hand in the wave that are worth an enqueue round of their own
+#endif
+constexpr unsigned kJobRing = 256;     // entries per wave: fewer than 64 pending before a round adds at most 3 * 64
+constexpr unsigned kJobUnitBits = 26;  // a job is owner lane << 26 | first unit of the triangle
+static_assert(kJobRing >= 64 + 64 * kWideLeafTris && (kJobRing & (kJobRing - 1)) == 0, "ring size");
+
+// Distances as unsigned keys that order like the floats.  NONNEG: every accepted distance is >= +0
+// (the ray's near is not negative), so the bits themselves do.
+template <bool NONNEG>
+__device__ __forceinline__ unsigned dist_key(float t)
+{
+    const unsigned b = __float_as_uint(t);
+    return NONNEG ? b : b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+template <bool NONNEG>
+__device__ __forceinline__ float key_dist(unsigned k)
+{
+    return __uint_as_float(NONNEG ? k : k ^ ((unsigned)((int)~k >> 31) | 0x80000000u));
+}
+
+struct JobQueue {
+    unsigned *ring;  // this wave's kJobRing job words
+    unsigned *slots; // this wave's result slots: closest-hit {triangle id, distance key} per lane, any-hit one flag per lane
+    unsigned head, tail; // free-running, wave-uniform: jobs [head, tail) are pending
+};
+
+template <bool ANYHIT, bool NONNEG>
+__device__ __forceinline__ void job_slot_init(const JobQueue &jq, unsigned lane, float far_t)
+{
+    if (ANYHIT) {
+        jq.slots[lane] = 0u;
+    } else {
+        jq.slots[2 * lane] = 0xFFFFFFFFu;
+        jq.slots[2 * lane + 1] = dist_key<NONNEG>(far_t);
+    }
+}
+
+// One triangle phase: the first min(pending, 64) jobs, one per lane.  job_issue() starts the
+// triangle loads and job_finish() tests, so that a node step's loads can be in flight with them.
+struct JobLoads {
+    float4 t0, t1;
+    float2 t2;
+    unsigned owner, n;
+};
+__device__ __forceinline__ JobLoads job_issue(const float4 *__restrict__ items, const JobQueue &jq, unsigned lane)
+{
+    JobLoads j;
+    const unsigned pending = jq.tail - jq.head;
+    j.n = pending < 64u ? pending : 64u;
+    const bool mine = lane < j.n;
+    const unsigned job = mine ? jq.ring[(jq.head + lane) & (kJobRing - 1u)] : lane << kJobUnitBits;
+    j.owner = job >> kJobUnitBits;
+    const float4 *q = items + (job & ((1u << kJobUnitBits) - 1u));
+    j.t0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    j.t1 = j.t0;
+    j.t2 = make_float2(0.f, 0.f);
+    if (mine) {
+        j.t0 = q[0];
+        j.t1 = q[1];
+        j.t2 = *reinterpret_cast<const float2 *>(q + 2);
+    }
+    return j;
+}
+template <bool ANYHIT, bool NONNEG>
+__device__ __forceinline__ void job_finish(const JobLoads &j, const LaneState &s, JobQueue &jq, unsigned lane)
+{
+    const unsigned n = j.n, owner = j.owner;
+    const bool mine = lane < n;
+    const float4 t0 = j.t0, t1 = j.t1;
+    const float2 t2 = j.t2;
+    // the owner's ray, from the owner's registers (every lane takes part: a lane without a job reads its own)
+    const int a = (int)(owner << 2);
+    const V3 o = v3(__int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.o.x))),
+                    __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.o.y))),
+                    __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.o.z))));
+    const V3 d = v3(__int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.d.x))),
+                    __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.d.y))),
+                    __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.d.z))));
+    const float near_t = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.near_t)));
+    float far_t;
+    bool skip = !mine;
+    if (ANYHIT) {
+        far_t = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(s.r.far_t)));
+        skip = skip || jq.slots[owner] != 0u; // the owner's ray is already occluded
+    } else {
+        far_t = key_dist<NONNEG>(jq.slots[2 * owner + 1]);
+    }
+    if (!skip) {
+        const float t = tri_test(t0, t1, t2, o, d);
+        if (t >= near_t && t < far_t) {
+            if (ANYHIT) {
+                jq.slots[owner] = 1u;
+            } else {
+                // t + 0 turns an accepted -0 into +0, whose key orders
+                const unsigned long long v =
+                    ((unsigned long long)dist_key<NONNEG>(t + 0.f) << 32) | (unsigned long long)__float_as_uint(t2.y);
+                atomicMin(reinterpret_cast<unsigned long long *>(jq.slots) + owner, v);
+            }
+        }
+    }
+    jq.head += n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <bool ANYHIT, bool NONNEG>
+__device__ __forceinline__ void job_phase(const float4 *__restrict__ items, const LaneState &s, JobQueue &jq, unsigned lane)
+{
+    const JobLoads j = job_issue(items, jq, lane);
+    job_finish<ANYHIT, NONNEG>(j, s, jq, lane);
+}
+
+// s.tri holds the ray's job mark: the value of jq.tail after its last job was written; its jobs are
+// done when jq.head has reached the mark.  On return s.r.far_t and s.hit of every lane without
+// outstanding jobs are up to date.
+template <bool ANYHIT, bool NONNEG, class STACK>
+__device__ __forceinline__ void traverse_wide_queue(const SceneDev &sc, LaneState &s, STACK &st, JobQueue &jq,
+                                                    unsigned min_active, unsigned max_steps)
+{
+    const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
+    RayRegs &r = s.r;
+    const unsigned lane = lane_id();
+    unsigned cur = s.cur, mark = s.tri, steps = s.steps;
+
+    for (;;) {
+        const bool has_leaf = cur != kDone && (cur & 3u) != 0; // kDone has its low bits set
+        const bool walking = !(cur & 3u) && steps < max_steps;
+        const unsigned nl = (unsigned)__popcll(__ballot(has_leaf));
+        const unsigned nw = (unsigned)__popcll(__ballot(walking));
+        const unsigned pending = jq.tail - jq.head;
+
+        // what a triangle phase changes for the lane's own ray
+        auto refresh = [&]() {
+            if (ANYHIT) {
+                if (s.have_ray && jq.slots[lane] != 0u) { // occluded: the walk is over, jobs still pending are skipped
+                    s.hit = 1u;
+                    cur = kDone;
+                    st.sp = 0;
+                }
+            } else {
+                r.far_t = key_dist<NONNEG>(jq.slots[2 * lane + 1]);
+            }
+        };
+        if ((!RTC_Q_FUSE && pending >= 64u) || (pending != 0u && nl == 0u && nw < (unsigned)RTC_Q_NODE_MIN)) {
+            job_phase<ANYHIT, NONNEG>(items, s, jq, lane);
+            refresh();
+            continue;
+        }
+        if (nl != 0u && (nl >= (unsigned)RTC_Q_LEAF_MIN || nw < (unsigned)RTC_Q_NODE_MIN)) {
+            // one job per triangle of the leaves at hand, then on with the next deferred item
+            const unsigned count = has_leaf ? (cur & 3u) : 0u;
+#pragma unroll
+            for (unsigned k = 0; k < kWideLeafTris; k++) {
+                const bool p = count > k;
+                const unsigned long long m = __ballot(p);
+                if (p)
+                    jq.ring[(jq.tail + prefix_count(m)) & (kJobRing - 1u)] =
+                        (lane << kJobUnitBits) | ((cur >> 2) + kUnitsPerItem * k);
+                jq.tail += (unsigned)__popcll(m);
+            }
+            if (has_leaf) {
+                mark = jq.tail;
+                cur = pop_next<ANYHIT>(st, r.far_t);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        if (nw == 0u) break; // nothing pending, no leaf at hand, nobody walking
+        const bool busy = has_leaf || walking || (s.have_ray && (int)(jq.head - mark) < 0);
+        if ((unsigned)__popcll(__ballot(busy)) < min_active) break;
+        // a node step; with enough jobs pending their triangle loads are in flight beside the node loads
+        const bool fuse = RTC_Q_FUSE && pending >= (unsigned)RTC_Q_FUSE_MIN;
+        JobLoads jl;
+        if (fuse) jl = job_issue(items, jq, lane);
+        float4 a0, a1, a2;
+        if (walking) {
+            steps++;
+            load_item(items + (cur >> 2), a0, a1, a2);
+        }
+        if (fuse) {
+            job_finish<ANYHIT, NONNEG>(jl, s, jq, lane);
+            refresh(); // the step below already sees what the jobs found
+        }
+        if (walking && cur != kDone) {
+            if (qwide_step<ANYHIT>(a0, a1, a2, slab_ray_lean(s), r.near_t, r.far_t, st, cur))
+                cur = pop_next<ANYHIT>(st, r.far_t);
+        }
+    }
+    if (!ANYHIT) s.hit = jq.slots[2 * lane];
+    s.cur = cur;
+    s.tri = mark;
+    s.steps = steps;
+}
+
 // The items of one iteration of traverse_wide_split(): a triangle (40 bytes used) for the lanes in
 // tmask and a node for the lanes in nmask.  The six loads are always issued -- lanes without an
 // item of a kind are masked off through exec, not by a branch -- and one wait covers them all.
@@ -1353,6 +1580,7 @@ constexpr int kLdsDepth = RTC_LDS_STACK_DEPTH;
 // IO policies: how rays are read and results written.
 
 struct StreamIO { // rt_stream_ray arrays, the reference's StreamRay boundary
+    static constexpr bool kNearNonNegative = false; // callers' rays: any near
     rt_stream_ray_dev *rays;
     unsigned *hits;
     unsigned char *occluded;
@@ -1382,6 +1610,7 @@ struct StreamIO { // rt_stream_ray arrays, the reference's StreamRay boundary
 };
 
 struct QueueIO { // render pipeline queues
+    static constexpr bool kNearNonNegative = true; // the shade kernel's rays start at SHADOW_RAY_NEAR
     QRay *rays;
     unsigned *hit_ids;         // extend
     const ShadowInfo *infos;   // connect
@@ -1484,17 +1713,45 @@ struct TraceTune<true, false, 6, QueueIO> {
     static constexpr int lds_depth = RTC_TUNE_ANY6_LDS;
     static constexpr bool stack_dist = false;
 };
+// form 7 keeps a job ring (4 KB per block) and result slots (2 KB closest-hit, 1 KB any-hit) in LDS
+// beside the stacks: 19 + 1 + 4 + 2 = 26 KB per block for six blocks per CU, 16 + 1 + 4 + 1 = 22 KB for seven
+template <class IO>
+struct TraceTune<false, false, 7, IO> {
+    static constexpr int waves = RTC_TUNE_EXT7_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_EXT7_LDS;
+    static constexpr bool stack_dist = false;
+};
+template <class IO>
+struct TraceTune<true, false, 7, IO> {
+    static constexpr int waves = RTC_TUNE_ANY7_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_ANY7_LDS;
+    static constexpr bool stack_dist = false;
+};
 #endif
+
+// The allocation-free stream entry point sizes its fixed overflow area from RTC_LDS_STACK_DEPTH entries
+// in LDS: every closest-hit kernel it can launch (forms 0..4 and 6 on StreamIO) must keep that many.
+static_assert(TraceTune<false, false, 0, StreamIO>::lds_depth == kLdsDepth &&
+                  TraceTune<false, false, 1, StreamIO>::lds_depth == kLdsDepth &&
+                  TraceTune<false, false, 2, StreamIO>::lds_depth == kLdsDepth &&
+                  TraceTune<false, false, 3, StreamIO>::lds_depth == kLdsDepth &&
+                  TraceTune<false, false, 4, StreamIO>::lds_depth == kLdsDepth &&
+                  TraceTune<false, false, 6, StreamIO>::lds_depth == kLdsDepth,
+              "a StreamIO closest-hit kernel keeps fewer LDS stack entries than the fixed scratch assumes");
 
 template <bool ANYHIT, bool STATS, int MODE, class IO>
 __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)) void trace_kernel(SceneDev sc, IO io, const unsigned *n_ptr, unsigned n_val,
                                                       TraceLaunch tl)
 {
     constexpr int kDepth = TraceTune<ANYHIT, STATS, MODE, IO>::lds_depth;
-    constexpr bool kWide = MODE == 2 || MODE == 3 || MODE == 6; // forms on the quantized 4-wide tree
+    constexpr bool kWide = MODE == 2 || MODE == 3 || MODE == 6 || MODE == 7; // forms on the quantized 4-wide tree
+    constexpr bool kQueue = MODE == 7;                                       // triangle jobs through a wave-level ring
+    constexpr bool kNonNeg = IO::kNearNonNegative;
     constexpr bool kDist = TraceTune<ANYHIT, STATS, MODE, IO>::stack_dist && kWide && !ANYHIT;
     __shared__ unsigned lds_stack[Stack<kBlock, kDepth, kDist>::kLdsWords * kBlock];
     __shared__ unsigned lds_index[kBlock]; // queue position of the lane's ray: needed again only when it retires
+    __shared__ unsigned lds_jobs[kQueue ? kJobRing * (kBlock / 64) : 1];
+    __shared__ unsigned long long lds_slots[kQueue ? (ANYHIT ? kBlock / 2 : kBlock) : 1];
     const unsigned n = n_ptr ? *n_ptr : n_val;
     const unsigned gtid = blockIdx.x * kBlock + threadIdx.x;
     Stack<kBlock, kDepth, kDist> st;
@@ -1515,6 +1772,10 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
     s.cur = kDone;
     s.tri = s.tri_end = 0; // no leaf pending: form 6 walks a lane for as long as it has one
     s.have_ray = false;
+    JobQueue jq;
+    jq.ring = lds_jobs + (kQueue ? (threadIdx.x >> 6) * kJobRing : 0u);
+    jq.slots = reinterpret_cast<unsigned *>(lds_slots) + (kQueue ? (threadIdx.x >> 6) * (ANYHIT ? 64u : 128u) : 0u);
+    jq.head = jq.tail = 0;
 
     while (true) {
         // ---- refill idle lanes
@@ -1554,6 +1815,10 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
                 lane_begin(s, kWide ? sc.wroot_ref : sc.root_ref, loaded, 0u);
                 lds_index[threadIdx.x] = ray;
                 st.sp = 0;
+                if (kQueue) {
+                    s.tri = jq.head; // no job outstanding
+                    job_slot_init<ANYHIT, kNonNeg>(jq, lane, loaded.far_t);
+                }
                 // A ray with a NaN or infinite origin or direction component cannot be accepted by
                 // the triangle test (its determinant is not finite), but NaN slab distances drop every
                 // box constraint and it would walk the whole tree.  It is retired as the miss it is;
@@ -1586,12 +1851,16 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             traverse_wide_steps<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else if (MODE == 6)
             traverse_wide_split<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+        else if (MODE == 7)
+            traverse_wide_queue<ANYHIT, kNonNeg>(sc, s, st, jq, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else
             traverse_steps<ANYHIT, STATS, (MODE == 4)>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
 
         // ---- stragglers: rays that used up their step budget are finished by the whole wave
         {
-            const bool inside_leaf = (MODE == 2 || MODE == 6) ? (s.tri & 3u) != 0 : s.tri < s.tri_end;
+            // form 7: a ray is handed over once its triangle jobs are done (a leaf at hand goes with it)
+            const bool inside_leaf = kQueue ? (int)(jq.head - s.tri) < 0
+                                            : (MODE == 2 || MODE == 6) ? (s.tri & 3u) != 0 : s.tri < s.tri_end;
             unsigned long long parked = __ballot(s.have_ray && s.cur != kDone && s.steps >= tl.coop_steps && !inside_leaf);
             CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
             while (parked != 0) {
@@ -1604,8 +1873,9 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             }
         }
 
-        // ---- retire finished rays (form 6: the walk can be done while the last leaf is still pending)
-        if (s.have_ray && s.cur == kDone && !(MODE == 6 && (s.tri & 3u))) {
+        // ---- retire finished rays (forms 6 and 7: the walk can be done while triangles are still pending)
+        if (kQueue && (int)(jq.head - s.tri) >= 0) s.tri = jq.head; // marks of lanes without jobs follow the ring
+        if (s.have_ray && s.cur == kDone && !(MODE == 6 && (s.tri & 3u)) && !(kQueue && (int)(jq.head - s.tri) < 0)) {
             s.index = lds_index[threadIdx.x];
             io.template store<ANYHIT>(s);
             s.have_ray = false;
@@ -2238,6 +2508,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(ShadeArgs a)
 // leaves hit id and distance per slot; shade_kernel rebuilds ray and PathInfo from the slot in
 // the same way.  A slot outside the image gets a NaN direction, which the fetch retires as a miss.
 struct PrimaryIO {
+    static constexpr bool kNearNonNegative = true; // camera rays start at 0
     CameraDev cam;
     PassDev ps;
     unsigned *hit_ids;
@@ -2379,14 +2650,19 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
                                n_val, tl);
         return;
     }
-    if ((tl.mode == 2 || tl.mode == 3 || tl.mode == 6) && !stats && sc.witems) {
+    if ((tl.mode == 2 || tl.mode == 3 || tl.mode == 6 || tl.mode == 7) && !stats && sc.witems) {
         // 4-wide tree, no visit counters in these forms
-        if (tl.mode == 6) {
+        if (tl.mode == 7 && tl.job_units_ok) {
+            if (anyhit)
+                launch_one<true, false, 7, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+            else
+                launch_one<false, false, 7, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+        } else if (tl.mode == 6) {
             if (anyhit)
                 launch_one<true, false, 6, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
             else
                 launch_one<false, false, 6, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
-        } else if (tl.mode == 2) {
+        } else if (tl.mode == 2 || tl.mode == 7) {
             if (anyhit)
                 launch_one<true, false, 2, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
             else

@@ -123,7 +123,9 @@ struct rt_ctx {
     // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
     // while-while form wins), [1] for deeper launches and the stream entry points
     unsigned fast_tree_buckets = 32; // >= 2: the fast forms get a tree from the search builder with that many buckets; 0: the reference's tree
+    unsigned fast_tree_max_leaf = kWideLeafTris; // most triangles in a leaf of the fast forms' tree (1..3)
     unsigned trav_mode[2] = {3, 2};
+    unsigned trav_deep_connect = 0xFFFFFFFFu; // form of the deeper any-hit launches; 0xFFFFFFFF: trav_mode[1]
     // the stream entry points are the reference's Bvh::intersect_stream / occluded_stream
     // boundary and walk the reference's binary tree unless told otherwise
     unsigned trav_stream = 1;
@@ -171,6 +173,7 @@ struct rt_scene {
     uint32_t num_triangles = 0;
     DevBuf nodes, witems, tris, big, normals;
     uint32_t num_wide_nodes = 0;
+    uint32_t num_wide_units = 0; // 16-byte units of the wide tree's item array
     uint32_t stack_bound = 0; // entries a lane's traversal stack can need on this scene
     SceneDev dev{};
     uint64_t device_bytes = 0;
@@ -225,6 +228,8 @@ static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl)
     // of a lane's whole stack and one batch of 64
     const unsigned reserve = std::max(sc->dev.max_depth + 2u, 3u * sc->dev.wmax_depth + 8u);
     tl.coop_steps = (reserve + 4u * 64u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
+    // a triangle job of the queued form holds a unit index in 26 bits (1 GB of wide-tree items)
+    tl.job_units_ok = sc->num_wide_units < (1u << 26) ? 1u : 0u;
 }
 
 static int timed_begin(rt_ctx *ctx, int kind, hipStream_t s, size_t *slot)
@@ -297,7 +302,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_FUSE_PRIMARY")) ctx->fuse_primary = atoi(env) ? 1u : 0u;
     if (const char *env = getenv("RTCORE_TRAVERSAL_STREAM")) {
         int v = atoi(env);
-        if (v >= 0 && v <= 6) ctx->trav_stream = (unsigned)v;
+        if (v >= 0 && v <= 7) ctx->trav_stream = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
         int v = atoi(env);
@@ -305,7 +310,11 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP")) {
         int v = atoi(env);
-        if ((v >= 0 && v <= 3) || v == 5 || v == 6) ctx->trav_mode[1] = (unsigned)v;
+        if ((v >= 0 && v <= 3) || (v >= 5 && v <= 7)) ctx->trav_mode[1] = (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP_CONNECT")) {
+        int v = atoi(env);
+        if ((v >= 0 && v <= 3) || (v >= 5 && v <= 7)) ctx->trav_deep_connect = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_SORT_EXTEND_FROM")) ctx->sort_from_depth[0] = (unsigned)atoi(env);
     if (const char *env = getenv("RTCORE_SORT_CONNECT_FROM")) ctx->sort_from_depth[1] = (unsigned)atoi(env);
@@ -413,12 +422,16 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->fuse_primary = (unsigned)value;
     } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
         ctx->fast_tree_buckets = (unsigned)value;
-    } else if (n == "traversal_stream" && in(0, 6)) {
+    } else if (n == "fast_tree_max_leaf" && in(1, kWideLeafTris)) {
+        ctx->fast_tree_max_leaf = (unsigned)value;
+    } else if (n == "traversal_stream" && in(0, 7)) {
         ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
         ctx->trav_mode[0] = (unsigned)value;
-    } else if (n == "traversal_deep" && (in(0, 3) || value == 5 || value == 6)) {
+    } else if (n == "traversal_deep" && (in(0, 3) || in(5, 7))) {
         ctx->trav_mode[1] = (unsigned)value;
+    } else if (n == "traversal_deep_connect" && (value == -1 || in(0, 3) || in(5, 7))) {
+        ctx->trav_deep_connect = value < 0 ? 0xFFFFFFFFu : (unsigned)value;
     } else if (n == "sort_extend_from" && in(0, 0xFFFFFFFFll)) {
         ctx->sort_from_depth[0] = (unsigned)value;
     } else if (n == "sort_connect_from" && in(0, 0xFFFFFFFFll)) {
@@ -657,7 +670,7 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         if (v >= 1 && v <= 256) threads = (unsigned)v;
     }
     // the wide tree is built over a copy of a tree whose larger leaves are split further
-    unsigned leaf_tris = kWideLeafTris;
+    unsigned leaf_tris = ctx->fast_tree_max_leaf;
     if (const char *env = getenv("RTCORE_WIDE_LEAF_TRIS")) {
         int v = atoi(env);
         if (v >= 1 && v <= (int)kWideLeafTris) leaf_tris = (unsigned)v;
@@ -780,6 +793,7 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         return fail(RT_ERR_LIMIT, "rt_scene_create: %u units in the wide tree, limit is 2^30", layout.num_units);
     std::vector<Unit> items;
     pack_wide4(wn, layout, xdt.data(), num_triangles, items);
+    sc->num_wide_units = (uint32_t)items.size();
     phase("layout + quantize + pack");
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
     if (rc == RT_OK) rc = upload(sc->witems, items.data(), items.size() * sizeof(Unit));
@@ -1124,7 +1138,8 @@ extern "C" int rt_intersect_stream_noalloc(rt_scene *sc, rt_stream_ray *d_rays, 
     // the fetch counters must start at zero; the stack area needs no clearing (entries are written
     // before they are read)
     HIP_TRY(hipMemsetAsync(fetch, 0, kNaFetchBytes, s));
-    const unsigned mode = ctx->trav_stream == 5 ? 2u : ctx->trav_stream; // the two-ray form keeps two stacks per lane
+    // the two-ray form keeps two stacks per lane and the queued form fewer LDS entries than the scratch is sized for
+    const unsigned mode = (ctx->trav_stream == 5 || ctx->trav_stream == 7) ? 2u : ctx->trav_stream;
     // no statistics, no launch timing (events are created on demand), no straggler hand-off (its
     // work stacks are far larger than this scratch)
     TraceLaunch tl{fetch, ovf, nullptr, ctx->min_active[1][0], mode, nullptr, 0, nullptr, 0, 0xFFFFFFFFu, 0};
@@ -1615,7 +1630,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_begin(ctx, 1, s, &slot);
                 if (rc != RT_OK) return rc;
                 TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[b == 0 ? 0 : 1][1],
-                                ctx->trav_mode[b == 0 ? 0 : 1], perm_connect, perm_connect_n, nullptr, 0, 0, b};
+                                (b != 0 && ctx->trav_deep_connect != 0xFFFFFFFFu) ? ctx->trav_deep_connect
+                                                                                   : ctx->trav_mode[b == 0 ? 0 : 1],
+                                perm_connect, perm_connect_n, nullptr, 0, 0, b};
                 fill_coop(ctx, sc, tlc);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
                                n_sh(b), ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);

@@ -53,7 +53,7 @@ def check_closest(O, sc, So, rays, io, to, ig, tg, rt, n_ordinary):
     return int(diff.size)
 
 
-@pytest.mark.parametrize("form", [2, 3, 5, 6])
+@pytest.mark.parametrize("form", [2, 3, 5, 6, 7])
 @pytest.mark.parametrize("coop", [0, 5, 4096])
 def test_wide_trace_parity(O, rt, ctx_default, scenes, coop, form):
     ctx = ctx_default
@@ -113,7 +113,7 @@ def test_wide_stats_request_runs_binary_form(O, rt, ctx, scenes):
 
 @pytest.mark.parametrize("name,kw,W,H,spp,b", [("cornell-class", {}, 96, 54, 4, 2),
                                                ("test-mesh", {"n_tris": 4000, "seed": 9}, 80, 45, 4, 3)])
-@pytest.mark.parametrize("forms", [(3, 2), (2, 3), (3, 5), (3, 6)])
+@pytest.mark.parametrize("forms", [(3, 2), (2, 3), (3, 5), (3, 6), (3, 7)])
 def test_wide_render_parity(O, rt, ctx_default, scenes, name, kw, W, H, spp, b, forms):
     ctx = ctx_default
     sc = scenes.load(name, **kw)
@@ -157,7 +157,7 @@ def test_full_size_fast_mode_against_exact_mode(rt, ctx, ctx_default, scenes, na
     assert rmse < 2e-3, rmse
 
 
-@pytest.mark.parametrize("form", [2, 3, 5, 6])
+@pytest.mark.parametrize("form", [2, 3, 5, 6, 7])
 def test_fast_forms_on_degenerate_leaves(O, rt, ctx_default, scenes, form):
     """A mesh whose tree has a root leaf, and one with clusters of 20 coincident triangles inside a
     larger mesh (leaves beyond 8 triangles in both builders): the fast forms still find the oracle's hits."""
