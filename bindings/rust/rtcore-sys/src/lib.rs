@@ -350,6 +350,7 @@ extern "C" {
     pub fn rt_ctx_last_max_ray_steps(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
     pub fn rt_ctx_last_depth_stats(ctx: *mut rt_ctx, out: *mut rt_depth_stats) -> c_int;
     pub fn rt_ctx_last_max_stack_entries(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
+    pub fn rt_ctx_last_pass_paths(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
 }
 
 // Layout checks against the sizes include/rtcore.h implies.

@@ -190,12 +190,19 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       reference's (binned SAH) but with that many buckets, every axis tried and
  *                       leaves of at most "fast_tree_max_leaf" triangles; 0 collapses it from the
  *                       reference's tree.  Forms 0 and 1 always walk the reference's tree.
- *   "fast_tree_max_leaf" 1..3 (default 3), read by rt_scene_create: most triangles in a leaf of
+ *   "fast_tree_max_leaf" 1..3 (default 2), read by rt_scene_create: most triangles in a leaf of
  *                       the tree of forms 2 and 3
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
  *                       (defaults: never = 0xFFFFFFFF for the bounce rays, 1 for the shadow rays)
  *   "sort_bits"         3..30 key bits that take part in the order
- *   "timing"            0/1 per-launch HIP events */
+ *   "timing"            0/1 per-launch HIP events
+ *   "overlap_connect"   0/1 (default 0): rt_render runs the any-hit launch of depth d on a stream of
+ *                       the context's own beside the closest-hit launch of depth d + 1, so that the tail
+ *                       of one persistent launch can be filled by the start of the other.  Same image bit
+ *                       for bit.  Per-launch event times then overlap and no longer add up to the frame.
+ *                       Measured 0.7-1 % slower on one GPU, hence off.
+ *   "workspace_limit_mb" test hook: a render workspace beyond this many MiB counts as an allocation
+ *                       failure (0 = off), which exercises the smaller-pass fallback of rt_render */
 int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value);
 
 /* Upper bound of paths per render pass, 4096..2^30 (default 2^28: a 1920x1080 frame at 128 samples
@@ -338,8 +345,8 @@ int rt_intersect_stream_device(rt_scene *scene, rt_stream_ray *d_rays, uint32_t 
  * creation or other allocating call.  The price: a grid of 512 blocks instead of every resident
  * one, no straggler hand-off (option "coop_steps" is not used), and two limits, beyond which the
  * call returns RT_ERR_LIMIT: n <= RT_NOALLOC_MAX_RAYS, and a scene whose trees can defer at most
- * RT_NOALLOC_MAX_STACK nodes per ray (tree depth + 1 for the binary forms; the stand-in scenes need
- * 24 to 46).  All calls on one GPU share the array: calls that overlap there (two streams, two
+ * RT_NOALLOC_MAX_STACK nodes per ray of the selected form (tree depth + 1 for the binary forms, three
+ * times the depth of the 4-wide tree + 1 for the others; the stand-in scenes need 24 to 46).  All calls on one GPU share the array: calls that overlap there (two streams, two
  * contexts, two threads) race; calls on one stream, or otherwise ordered, are fine. */
 #define RT_NOALLOC_MAX_RAYS 268435456u /* 2^28 */
 #define RT_NOALLOC_MAX_STACK 56
@@ -470,6 +477,12 @@ int rt_ctx_last_max_ray_steps(rt_ctx *ctx, uint64_t out[2]);
  * ones in a global overflow area sized from the scene's tree depth, so any depth up to 1024 works. */
 #define RT_LDS_STACK_ENTRIES 24
 int rt_ctx_last_max_stack_entries(rt_ctx *ctx, uint64_t out[2]);
+
+/* Path slots per pass the last rt_render / rt_render_device call planned with (no counterpart in
+ * the reference).  At most the context's max_paths; smaller when the workspace for a pass of that
+ * size could not be allocated: the call then releases what it had grown, halves the pass and plans
+ * the frame again (down to one tile or 2^16 paths) before it gives up with RT_ERR_NOMEM. */
+int rt_ctx_last_pass_paths(rt_ctx *ctx, uint64_t *out);
 
 #ifdef __cplusplus
 }

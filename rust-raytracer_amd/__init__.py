@@ -123,6 +123,7 @@ EXPORTS = {
     "rt_ctx_last_max_ray_steps": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
     "rt_ctx_last_depth_stats": (C.c_int, [_vp, C.POINTER(DepthStats * 2)]),
     "rt_ctx_last_max_stack_entries": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
+    "rt_ctx_last_pass_paths": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "rt_ctx_last_stats_split": (C.c_int, [_vp, C.POINTER(TraceStats * 2)]),
     "rt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
@@ -346,6 +347,13 @@ class Context:
         out = (DepthStats * 2)()
         _check(_lib.rt_ctx_last_depth_stats(self.h, C.byref(out)))
         return out[0].as_dict(), out[1].as_dict()
+
+    def last_pass_paths(self):
+        """Path slots per pass the last render call planned with (smaller than max_paths after a
+        failed workspace allocation)."""
+        out = C.c_uint64(0)
+        _check(_lib.rt_ctx_last_pass_paths(self.h, C.byref(out)))
+        return int(out.value)
 
     def last_max_stack_entries(self):
         out = (C.c_uint64 * 2)()

@@ -97,6 +97,9 @@
 #ifndef RTC_WW_NODE_MIN
 #define RTC_WW_NODE_MIN 40
 #endif
+#ifndef RTC_WW_NODE_RELATIVE
+#define RTC_WW_NODE_RELATIVE 1
+#endif
 // Fewest LDS stack entries any trace kernel keeps per lane: the global overflow area holds the
 // entries beyond that, so it is sized from this value.
 #define RTC_MIN2_(a, b) ((a) < (b) ? (a) : (b))

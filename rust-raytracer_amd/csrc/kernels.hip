@@ -1123,6 +1123,14 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
     unsigned steps = s.steps;
 
     while (cur != kDone && steps < max_steps) {
+        // the early exit below is relative to the lanes that enter the node loop (RTC_WW_NODE_MIN of 64): with
+        // an absolute count a wave that enters with fewer lanes (launch tail, small frames, just before a
+        // refill) would leave the loop after every single node
+#if RTC_WW_NODE_RELATIVE
+        const unsigned node_min = ((unsigned)__popcll(__ballot(!(cur & 3u))) * (unsigned)RTC_WW_NODE_MIN) >> 6;
+#else
+        const unsigned node_min = (unsigned)RTC_WW_NODE_MIN;
+#endif
         while (!(cur & 3u) && steps < max_steps) { // kDone has its low bits set
             steps++;
             const unsigned ucur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
@@ -1139,7 +1147,7 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
             }
             if (pop) cur = pop_next<ANYHIT>(st, r.far_t);
             // the last few lanes still descending do not hold up the lanes that wait at their leaves
-            if (RTC_WW_NODE_MIN > 1 && (unsigned)__popcll(__ballot(!(cur & 3u))) < (unsigned)RTC_WW_NODE_MIN) break;
+            if (RTC_WW_NODE_MIN > 1 && (unsigned)__popcll(__ballot(!(cur & 3u))) < node_min) break;
         }
         if (cur != kDone && (cur & 3u)) {
             steps++;

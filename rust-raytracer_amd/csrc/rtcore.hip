@@ -95,6 +95,13 @@ struct Workspace {
     DevBuf rays[2], infos[2], hit_ids, hit_t, shadow_rays, shadow_infos, rad, counters;
     DevBuf keys[2], keys_sorted, perm[2], sort_temp; // [0] bounce queue, [1] shadow queue
     uint64_t paths = 0;
+    void release_all()
+    {
+        for (DevBuf *b : {&rays[0], &rays[1], &infos[0], &infos[1], &hit_ids, &hit_t, &shadow_rays, &shadow_infos, &rad,
+                          &counters, &keys[0], &keys[1], &keys_sorted, &perm[0], &perm[1], &sort_temp})
+            b->release();
+        paths = 0;
+    }
 };
 
 } // namespace
@@ -108,8 +115,16 @@ struct rt_ctx {
     int num_cus = 0;
     unsigned max_blocks = 0; // resident trace blocks
     hipStream_t stream = nullptr;
-    DevBuf ovf;             // traversal stack overflow area
-    unsigned ovf_depth = 0; // entries per thread available in ovf
+    DevBuf ovf;             // traversal stack overflow area: two halves, one per stream that runs trace kernels
+    unsigned ovf_depth = 0; // entries per thread available in each half of ovf
+    // 1: rt_render runs the any-hit launch of depth d on a stream of its own beside the closest-hit launch of
+    // depth d + 1 (they share nothing but the scene), so that the tail of one persistent launch -- its last
+    // rays finishing at low occupancy -- could be filled by the start of the other.  Measured on one GPU it is
+    // 0.7 % slower on the full San-Miguel-class frame and 1 % slower on an eighth of it (the two kernels end up
+    // sharing the CUs for most of their run instead of meeting at the tail), so it is off by default.
+    unsigned overlap_connect = 0;
+    hipStream_t conn_stream = nullptr;
+    std::vector<hipEvent_t> ev_shade, ev_conn; // per depth: shade + sorts done (launch stream), connect done (conn_stream)
     DevBuf dstats;
     DevBuf fetch; // ray-fetch counters of the stream entry points
     DevBuf coop;  // wave-private work stacks of the cooperative straggler path
@@ -123,7 +138,9 @@ struct rt_ctx {
     // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
     // while-while form wins), [1] for deeper launches and the stream entry points
     unsigned fast_tree_buckets = 32; // >= 2: the fast forms get a tree from the search builder with that many buckets; 0: the reference's tree
-    unsigned fast_tree_max_leaf = kWideLeafTris; // most triangles in a leaf of the fast forms' tree (1..3)
+    // most triangles in a leaf of the fast forms' tree (1..3): 2 against 3 is +2 % on San-Miguel-class, +1 % on
+    // dragon-class, nothing on Sponza-class; 1 gains on the deep launches and loses more on the depth-0 ones
+    unsigned fast_tree_max_leaf = 2;
     unsigned trav_mode[2] = {3, 2};
     unsigned trav_deep_connect = 0xFFFFFFFFu; // form of the deeper any-hit launches; 0xFFFFFFFF: trav_mode[1]
     // the stream entry points are the reference's Bvh::intersect_stream / occluded_stream
@@ -149,6 +166,9 @@ struct rt_ctx {
     // in one pass (48 GB of workspace on a 288 GB GPU); the persistent trace launches pay their ramp and tail
     // once per launch, so one pass of 2^28 paths is 5-8 % faster than four of 2^26.
     uint64_t max_paths = 1ull << 28;
+    // test hook: a render workspace beyond this many bytes counts as an allocation failure (0 = no limit)
+    uint64_t workspace_limit = 0;
+    uint64_t last_pass_paths = 0; // path slots per pass the last render call planned with
     DevBuf io_a, io_b; // staging for the host-buffer entry points
     // rt_intersect_stream / rt_occluded_stream work through their rays in chunks: while chunk k is
     // traced, chunk k+1 is uploaded on `copy_stream` and the results of chunk k-1 (hit ids and far
@@ -210,7 +230,7 @@ static int ensure_overflow(rt_ctx *ctx, unsigned max_depth)
     need = std::max(need, 2u * (max_depth + 1 > dual_lds ? max_depth + 1 - dual_lds : 1u));
     if (need <= ctx->ovf_depth) return RT_OK;
     size_t threads = (size_t)ctx->max_blocks * RTC_TRACE_BLOCK;
-    int rc = ctx->ovf.ensure(threads * need * sizeof(unsigned));
+    int rc = ctx->ovf.ensure(2 * threads * need * sizeof(unsigned));
     if (rc != RT_OK) return rc;
     ctx->ovf_depth = need;
     return RT_OK;
@@ -218,9 +238,11 @@ static int ensure_overflow(rt_ctx *ctx, unsigned max_depth)
 
 // cooperative-finish settings of a launch on `sc`: off when the tree is too deep
 // for the fixed work-stack capacity
-static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl)
+static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl, bool second_set = false)
 {
-    tl.coop = ctx->coop.p;
+    // the second set of work stacks belongs to launches on the context's connect stream
+    tl.coop = (char *)ctx->coop.p +
+              (second_set ? (size_t)ctx->max_blocks * (RTC_TRACE_BLOCK / 64) * ctx->coop_cap * 8 : 0); // 8 bytes per work-stack entry
     tl.coop_cap = ctx->coop_cap;
     // the work stack takes over a lane's whole traversal stack and then needs the
     // headroom coop_finish documents
@@ -282,18 +304,19 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     ctx->max_blocks = (unsigned)(ctx->num_cus * per_cu);
     if (const char *env = getenv("RTCORE_NO_TIMING")) ctx->timing = !(env[0] == '1');
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->conn_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(RT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
+    if (const char *env = getenv("RTCORE_OVERLAP_CONNECT")) ctx->overlap_connect = atoi(env) ? 1u : 0u;
+    // RTCORE_MIN_ACTIVE, like the option "min_active": the deeper launches and the stream entry points;
+    // RTCORE_MIN_ACTIVE_EXTEND / _CONNECT: one kind of them; RTCORE_MIN_ACTIVE_DEPTH0, like
+    // "min_active_depth0": the depth-0 launches of rt_render
     if (const char *env = getenv("RTCORE_MIN_ACTIVE")) {
         int v = atoi(env);
-        if (v >= 1 && v <= 64)
-            ctx->min_active[0][0] = ctx->min_active[0][1] = ctx->min_active[1][0] = ctx->min_active[1][1] = (unsigned)v;
-    }
-    if (const char *env = getenv("RTCORE_MIN_ACTIVE_DEPTH0")) {
-        int v = atoi(env);
-        if (v >= 1 && v <= 64) ctx->min_active[0][0] = ctx->min_active[0][1] = (unsigned)v;
+        if (v >= 1 && v <= 64) ctx->min_active[1][0] = ctx->min_active[1][1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL")) {
         int v = atoi(env);
@@ -328,11 +351,16 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_MIN_ACTIVE_EXTEND")) {
         int v = atoi(env);
-        if (v >= 1 && v <= 64) ctx->min_active[0][0] = ctx->min_active[1][0] = (unsigned)v;
+        if (v >= 1 && v <= 64) ctx->min_active[1][0] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_MIN_ACTIVE_CONNECT")) {
         int v = atoi(env);
-        if (v >= 1 && v <= 64) ctx->min_active[0][1] = ctx->min_active[1][1] = (unsigned)v;
+        if (v >= 1 && v <= 64) ctx->min_active[1][1] = (unsigned)v;
+    }
+    // the depth-0 launches have their own threshold: parsed last, and the variables above leave it alone
+    if (const char *env = getenv("RTCORE_MIN_ACTIVE_DEPTH0")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64) ctx->min_active[0][0] = ctx->min_active[0][1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_COOP_CAP")) {
         int v = atoi(env);
@@ -341,7 +369,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     int rc = ctx->dstats.ensure(2 * sizeof(StatsDev));
     if (rc == RT_OK) rc = ctx->fetch.ensure(kFetchUints * sizeof(unsigned));
     if (rc == RT_OK)
-        rc = ctx->coop.ensure((size_t)ctx->max_blocks * (RTC_TRACE_BLOCK / 64) * ctx->coop_cap * 8);
+        rc = ctx->coop.ensure(2 * (size_t)ctx->max_blocks * (RTC_TRACE_BLOCK / 64) * ctx->coop_cap * 8); // one set per stream
     if (rc == RT_OK) rc = ensure_overflow(ctx, 0);
     if (rc == RT_OK && hipHostMalloc((void **)&ctx->h_counts, kMaxQueueCounters * sizeof(uint32_t)) != hipSuccess)
         rc = fail(RT_ERR_NOMEM, "rt_ctx_create: pinned host allocation failed");
@@ -373,6 +401,9 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     }
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->counts_ready) (void)hipEventDestroy(ctx->counts_ready);
+    for (hipEvent_t ev : ctx->ev_shade) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->ev_conn) (void)hipEventDestroy(ev);
+    if (ctx->conn_stream) (void)hipStreamDestroy(ctx->conn_stream);
     ctx->ovf.release();
     ctx->dstats.release();
     ctx->fetch.release();
@@ -388,12 +419,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
         if (ctx->out_done[k]) (void)hipEventDestroy(ctx->out_done[k]);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-    Workspace &w = ctx->ws;
-    w.rays[0].release(); w.rays[1].release(); w.infos[0].release(); w.infos[1].release();
-    w.hit_ids.release(); w.hit_t.release(); w.shadow_rays.release(); w.shadow_infos.release(); w.rad.release();
-    w.counters.release();
-    w.keys[0].release(); w.keys[1].release(); w.keys_sorted.release();
-    w.perm[0].release(); w.perm[1].release(); w.sort_temp.release();
+    ctx->ws.release_all();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -418,6 +444,10 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->min_active[1][0] = ctx->min_active[1][1] = (unsigned)value;
     } else if (n == "min_active_depth0" && in(1, 64)) {
         ctx->min_active[0][0] = ctx->min_active[0][1] = (unsigned)value;
+    } else if (n == "workspace_limit_mb" && in(0, 1 << 20)) {
+        ctx->workspace_limit = (uint64_t)value << 20;
+    } else if (n == "overlap_connect" && in(0, 1)) {
+        ctx->overlap_connect = (unsigned)value;
     } else if (n == "fuse_primary" && in(0, 1)) {
         ctx->fuse_primary = (unsigned)value;
     } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
@@ -528,6 +558,13 @@ extern "C" int rt_ctx_last_launch_ms(rt_ctx *ctx, float *ms, uint32_t *kind, uin
         ms[i] = v;
         kind[i] = (uint32_t)t.kind;
     }
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_last_pass_paths(rt_ctx *ctx, uint64_t *out)
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_ctx_last_pass_paths: NULL argument");
+    *out = ctx->last_pass_paths;
     return RT_OK;
 }
 
@@ -716,9 +753,18 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
             fn((size_t)0, n);
             return;
         }
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < T; t++) pool.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
-        for (auto &th : pool) th.join();
+        // threads already started are joined whatever happens (a later one may fail to start): a
+        // joinable std::thread that is destroyed terminates the process
+        struct Pool {
+            std::vector<std::thread> threads;
+            ~Pool()
+            {
+                for (auto &th : threads)
+                    if (th.joinable()) th.join();
+            }
+        } pool;
+        pool.threads.reserve(T);
+        for (unsigned t = 0; t < T; t++) pool.threads.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
     };
     auto make_tris = [&](const std::vector<uint32_t> &order, std::vector<DevTri> &dt) {
         dt.resize(num_triangles);
@@ -1124,11 +1170,19 @@ extern "C" int rt_intersect_stream_noalloc(rt_scene *sc, rt_stream_ray *d_rays, 
     if (n && (!d_rays || !d_hits)) return fail(RT_ERR_INVALID, "rt_intersect_stream_noalloc: NULL buffer");
     if (n > RT_NOALLOC_MAX_RAYS)
         return fail(RT_ERR_LIMIT, "rt_intersect_stream_noalloc: %u rays, limit is %u per call", n, RT_NOALLOC_MAX_RAYS);
-    if (sc->stack_bound > RT_NOALLOC_MAX_STACK)
-        return fail(RT_ERR_LIMIT,
-                    "rt_intersect_stream_noalloc: this scene's trees can defer %u nodes per ray, the fixed scratch holds %u",
-                    sc->stack_bound, (unsigned)RT_NOALLOC_MAX_STACK);
     rt_ctx *ctx = sc->ctx;
+    {
+        // deferred nodes a ray of the selected form can hold: one sibling per level of the binary tree, up to
+        // three children per level of the wide one
+        const unsigned form = ctx->trav_stream;
+        const bool wide = (form == 2 || form == 3 || form == 5 || form == 6 || form == 7) && sc->dev.witems;
+        const unsigned bound = wide ? 3u * sc->dev.wmax_depth + 1u : sc->dev.max_depth + 1u;
+        if (bound > RT_NOALLOC_MAX_STACK)
+            return fail(RT_ERR_LIMIT,
+                        "rt_intersect_stream_noalloc: rays of traversal form %u can defer %u nodes on this scene, the "
+                        "fixed scratch holds %u",
+                        form, bound, (unsigned)RT_NOALLOC_MAX_STACK);
+    }
     int rc = ctx_set_device(ctx);
     if (rc != RT_OK) return rc;
     if (n == 0) return RT_OK;
@@ -1387,6 +1441,13 @@ static int ensure_workspace(rt_ctx *ctx, uint64_t paths, uint32_t ncounters, boo
 {
     Workspace &w = ctx->ws;
     int rc = RT_OK;
+    if (ctx->workspace_limit) {
+        const uint64_t per_path = 2 * sizeof(QRay) + 2 * sizeof(PathInfo) + 2 * sizeof(uint32_t) + sizeof(QRay) +
+                                  sizeof(ShadowInfo) + 3 * sizeof(float) + (sorting ? 5 * sizeof(uint32_t) : 0);
+        if (paths * per_path > ctx->workspace_limit)
+            return fail(RT_ERR_NOMEM, "render workspace of %llu paths exceeds the workspace_limit_mb option",
+                        (unsigned long long)paths);
+    }
     for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.rays[i].ensure(paths * sizeof(QRay));
     for (int i = 0; i < 2 && rc == RT_OK; i++) rc = w.infos[i].ensure(paths * sizeof(PathInfo));
     if (rc == RT_OK) rc = w.hit_ids.ensure(paths * sizeof(uint32_t));
@@ -1432,26 +1493,10 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
         (uint32_t)((ntiles + shard_count - 1 - params->shard_index) / shard_count); // i % sc == si
     if (my_tiles == 0) return RT_OK;
 
-    // pass plan: tiles_per_pass tiles x k samples <= max_paths slots
-    uint64_t cap = ctx->max_paths;
-    if (cap < ts2) return fail(RT_ERR_LIMIT, "rt_render_device: max_paths %llu below one tile (%u)",
-                               (unsigned long long)cap, ts2);
-    uint32_t k = params->samples_per_pass ? params->samples_per_pass : 0;
-    uint32_t tiles_per_pass;
-    if ((uint64_t)my_tiles * ts2 <= cap) {
-        tiles_per_pass = my_tiles;
-        uint64_t kmax = cap / ((uint64_t)my_tiles * ts2);
-        if (k == 0 || k > kmax) k = (uint32_t)std::min<uint64_t>(kmax, 0xFFFFFFFFu);
-    } else {
-        k = 1;
-        tiles_per_pass = (uint32_t)(cap / ts2);
-    }
-    k = std::min(k, params->samples);
-    if (k < 1) k = 1;
-    const uint64_t slots = (uint64_t)tiles_per_pass * ts2 * k;
-    if (slots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rt_render_device: pass of %llu paths exceeds 2^32",
-                                           (unsigned long long)slots);
-
+    // pass plan: tiles_per_pass tiles x k samples <= cap slots.  The cap starts at max_paths; when the
+    // workspace for it cannot be allocated (a smaller or shared GPU, a large scene resident) what was
+    // grown so far is released and the frame is planned again with half the pass, down to one tile
+    // or 2^16 paths.
     const uint32_t nb = params->max_bounces + 1; // extend launches per pass
     // per pass: ray count per depth (nb+1), shadow count per depth (nb), then the
     // ray-fetch counters of the 2*nb trace launches; zeroed by one memset
@@ -1459,8 +1504,36 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
     const uint32_t ncounters = nqueue + 2 * nb * kFetchUints;
     // a queue consumed at depth d is sorted when d >= sort_from_depth
     const bool sort_any = (nb > ctx->sort_from_depth[0]) || (nb > ctx->sort_from_depth[1]);
-    rc = ensure_workspace(ctx, slots, ncounters, sort_any, ctx->sort_bits);
+    uint64_t cap = ctx->max_paths;
+    if (cap < ts2) return fail(RT_ERR_LIMIT, "rt_render_device: max_paths %llu below one tile (%u)",
+                               (unsigned long long)cap, ts2);
+    uint32_t k = 0, tiles_per_pass = 0;
+    uint64_t slots = 0;
+    for (;;) {
+        k = params->samples_per_pass ? params->samples_per_pass : 0;
+        if ((uint64_t)my_tiles * ts2 <= cap) {
+            tiles_per_pass = my_tiles;
+            uint64_t kmax = cap / ((uint64_t)my_tiles * ts2);
+            if (k == 0 || k > kmax) k = (uint32_t)std::min<uint64_t>(kmax, 0xFFFFFFFFu);
+        } else {
+            k = 1;
+            tiles_per_pass = (uint32_t)(cap / ts2);
+        }
+        k = std::min(k, params->samples);
+        if (k < 1) k = 1;
+        slots = (uint64_t)tiles_per_pass * ts2 * k;
+        if (slots > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rt_render_device: pass of %llu paths exceeds 2^32",
+                                               (unsigned long long)slots);
+        rc = ensure_workspace(ctx, slots, ncounters, sort_any, ctx->sort_bits);
+        if (rc != RT_ERR_NOMEM) break;
+        const uint64_t floor_paths = std::max<uint64_t>(ts2, 1u << 16);
+        if (slots <= floor_paths) break; // nothing smaller to try: the error stands
+        HIP_TRY(hipStreamSynchronize(s)); // nothing of this context may still be using the buffers
+        ctx->ws.release_all();
+        cap = std::max<uint64_t>(floor_paths, slots / 2);
+    }
     if (rc != RT_OK) return rc;
+    ctx->last_pass_paths = slots;
     Workspace &w = ctx->ws;
 
     const CameraDev cam = make_camera(*camera, params->width, params->height);
@@ -1473,6 +1546,18 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
     float *rad_r = (float *)w.rad.p, *rad_g = rad_r + slots, *rad_b = rad_g + slots;
     uint32_t *counters = (uint32_t *)w.counters.p;
     unsigned *ovf = (unsigned *)ctx->ovf.p;
+    // any-hit launches on their own stream, with their own overflow area and straggler work stacks
+    const bool overlap = ctx->overlap_connect && !visit;
+    hipStream_t sconn = overlap ? ctx->conn_stream : s;
+    unsigned *ovf_conn = overlap ? ovf + (size_t)ctx->max_blocks * RTC_TRACE_BLOCK * ctx->ovf_depth : ovf;
+    if (overlap)
+        while (ctx->ev_shade.size() < nb) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            ctx->ev_shade.push_back(a);
+            HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            ctx->ev_conn.push_back(b);
+        }
 
     const uint64_t plan_key[3] = {(uint64_t)(uintptr_t)sc, slots, nb};
     for (uint32_t tile0 = 0; tile0 < my_tiles; tile0 += tiles_per_pass) {
@@ -1553,6 +1638,9 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
                 if (want) launch_count_rays(n_ray(b), dstats, b, !visit, s);
+                // shade(b) rewrites the shadow queue and its sort buffers: the any-hit launch of depth b - 1,
+                // which ran beside this extend launch, must be through with them
+                if (overlap && b > 0) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_conn[b - 1], 0));
 
                 ShadeArgs a{};
                 a.rays_in = (const QRay *)w.rays[cur].p;
@@ -1627,20 +1715,26 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                 rc = timed_end(ctx, slot, s);
                 if (rc != RT_OK) return rc;
 
-                rc = timed_begin(ctx, 1, s, &slot);
+                if (overlap) {
+                    HIP_TRY(hipEventRecord(ctx->ev_shade[b], s));
+                    HIP_TRY(hipStreamWaitEvent(sconn, ctx->ev_shade[b], 0));
+                }
+                rc = timed_begin(ctx, 1, sconn, &slot);
                 if (rc != RT_OK) return rc;
-                TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf, dstats + 1, ctx->min_active[b == 0 ? 0 : 1][1],
+                TraceLaunch tlc{fetch + (size_t)(2 * b + 1) * kFetchUints, ovf_conn, dstats + 1, ctx->min_active[b == 0 ? 0 : 1][1],
                                 (b != 0 && ctx->trav_deep_connect != 0xFFFFFFFFu) ? ctx->trav_deep_connect
                                                                                    : ctx->trav_mode[b == 0 ? 0 : 1],
                                 perm_connect, perm_connect_n, nullptr, 0, 0, b};
-                fill_coop(ctx, sc, tlc);
+                fill_coop(ctx, sc, tlc, overlap);
                 launch_connect(visit, sc->dev, (const QRay *)w.shadow_rays.p, (const ShadowInfo *)w.shadow_infos.p,
-                               n_sh(b), ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, s);
-                rc = timed_end(ctx, slot, s);
+                               n_sh(b), ps.num_slots, rad_r, rad_g, rad_b, tlc, ctx->max_blocks, sconn);
+                rc = timed_end(ctx, slot, sconn);
                 if (rc != RT_OK) return rc;
-                if (want) launch_count_rays(n_sh(b), dstats + 1, b, !visit, s);
+                if (want) launch_count_rays(n_sh(b), dstats + 1, b, !visit, sconn);
+                if (overlap) HIP_TRY(hipEventRecord(ctx->ev_conn[b], sconn));
                 cur ^= 1;
             }
+            if (overlap) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_conn[nb - 1], 0)); // the radiance slots are complete
             rc = timed_begin(ctx, 2, s, &slot);
             if (rc != RT_OK) return rc;
             launch_accumulate(ps, rad_r, rad_g, rad_b, d_accum, s);

@@ -56,8 +56,8 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
                   unsigned align_mode = 0);
 
 // One node on the 8-bit grid.  Per axis: origin is placed `margin` below the lowest child plane
-// and the grid step is the smallest power of two with which byte 255 reaches `margin` above the
-// highest, where
+// and the grid step is the smallest value of the form (1 + m / 4) * 2^e, m in 0..3 (what the ten-bit step
+// code of DevQNode holds), with which byte 255 reaches `margin` above the highest, where
 //     margin = 2^-18 * max(|lowest|, |highest|, extent)
 // (several hundred times the rounding error of the traversal's
 // fma(byte, step/d, (origin - o)/d) against the exact plane); lower planes are

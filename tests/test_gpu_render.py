@@ -142,6 +142,58 @@ def test_fused_primary_is_bit_identical(rt, ctx, scenes):
     Sg.close()
 
 
+@pytest.mark.parametrize("which", ["ctx", "ctx_default"])
+def test_overlapped_connect_is_bit_identical(rt, request, scenes, which):
+    """The any-hit launch of depth d on its own stream beside the closest-hit launch of depth d + 1
+    (option overlap_connect) against one launch after the other on one stream: the same accumulator bit for bit
+    and the same ray counts, with several passes per frame, sorted and unsorted queues."""
+    c = request.getfixturevalue(which)
+    sc = scenes.load("test-mesh", n_tris=6000, seed=13)
+    Sg = rt.Scene(c, sc.positions, sc.indices, sc.geom_normals)
+    try:
+        for (W, H, spp, k, b, sort_from) in ((100, 57, 6, 2, 3, 1), (64, 36, 4, 0, 2, 0xFFFFFFFF), (80, 45, 3, 1, 0, 0)):
+            c.set_option("sort_connect_from", sort_from)
+            c.set_option("overlap_connect", 1)
+            a1, s1 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b, samples_per_pass=k)
+            a1b, _ = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b, samples_per_pass=k)
+            c.set_option("overlap_connect", 0)
+            a0, s0 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=b, samples_per_pass=k)
+            assert s1["total_rays"] == s0["total_rays"]
+            assert np.array_equal(a1, a0) and np.array_equal(a1b, a0)
+    finally:
+        c.set_option("overlap_connect", 0)
+        c.set_option("sort_connect_from", 1)
+    Sg.close()
+
+
+def test_workspace_allocation_fallback(rt, ctx_default, scenes):
+    """When the workspace of a pass of max_paths cannot be allocated the call releases what it had
+    grown, halves the pass and plans the frame again: forced here through the workspace_limit_mb
+    option.  Same ray total, accumulator equal up to the order of the per-pixel additions; a limit
+    below the smallest pass is still an RT_ERR_NOMEM."""
+    c = ctx_default
+    sc = scenes.load("test-mesh", n_tris=5000, seed=3)
+    Sg = rt.Scene(c, sc.positions, sc.indices, sc.geom_normals)
+    W, H, spp = 640, 360, 8
+    try:
+        full, st = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=2)
+        assert c.last_pass_paths() >= W * H * spp
+        c.set_option("workspace_limit_mb", 64)                      # about 350 k paths
+        small, s2 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=2)
+        assert (1 << 16) <= c.last_pass_paths() < W * H * spp // 4
+        assert s2["total_rays"] == st["total_rays"]
+        assert np.allclose(small, full, rtol=RTOL, atol=ATOL)
+        c.set_option("workspace_limit_mb", 1)                       # less than the floor of 2^16 paths needs
+        with pytest.raises(rt.RtError):
+            Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=2)
+        c.set_option("workspace_limit_mb", 0)
+        again, s3 = Sg.render(sc.camera, sc.light, W, H, spp, max_bounces=2)
+        assert np.array_equal(again, full) and s3["total_rays"] == st["total_rays"]
+    finally:
+        c.set_option("workspace_limit_mb", 0)
+    Sg.close()
+
+
 def test_queue_order_does_not_change_the_image(rt, ctx, scenes):
     """Morton-ordered or not, shadow and bounce queues give the same accumulator bit for bit (radiance
     is kept per path slot and summed in a fixed order) and the same ray counts."""
