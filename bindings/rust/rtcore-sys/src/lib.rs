@@ -351,6 +351,21 @@ extern "C" {
     pub fn rt_ctx_last_depth_stats(ctx: *mut rt_ctx, out: *mut rt_depth_stats) -> c_int;
     pub fn rt_ctx_last_max_stack_entries(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
     pub fn rt_ctx_last_pass_paths(ctx: *mut rt_ctx, out: *mut u64) -> c_int;
+    pub fn rt_bvh_build_search_device(
+        ctx: *mut rt_ctx,
+        positions: *const f32,
+        num_vertices: u32,
+        indices: *const u32,
+        num_triangles: u32,
+        buckets: u32,
+        max_leaf: u32,
+        nodes: *mut rt_flat_node,
+        order: *mut u32,
+        info: *mut rt_scene_info,
+        stats: *mut rt_bvh_stats,
+    ) -> c_int;
+    pub fn rt_scene_fast_tree_on_device(scene: *const rt_scene, out: *mut c_int) -> c_int;
+    pub fn rt_scene_bounds(scene: *const rt_scene, lo: *mut f32, hi: *mut f32) -> c_int;
 }
 
 // Layout checks against the sizes include/rtcore.h implies.

@@ -190,6 +190,9 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       reference's (binned SAH) but with that many buckets, every axis tried and
  *                       leaves of at most "fast_tree_max_leaf" triangles; 0 collapses it from the
  *                       reference's tree.  Forms 0 and 1 always walk the reference's tree.
+ *   "fast_tree_device_build" 0 = the tree of forms 2 and 3 is built on the host, 1 (default) = on the
+ *                       GPU for meshes of 2^18 triangles and more, 2 = always on the GPU.  The tree is the
+ *                       same either way (rt_bvh_build_search_device).
  *   "fast_tree_max_leaf" 1..3 (default 2), read by rt_scene_create: most triangles in a leaf of
  *                       the tree of forms 2 and 3
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
@@ -244,6 +247,22 @@ int rt_bvh_build_host(const float *positions, uint32_t num_vertices, const uint3
 int rt_bvh_build_search_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,
                              uint32_t num_triangles, uint32_t threads, uint32_t buckets, uint32_t max_leaf,
                              rt_flat_node *nodes, uint32_t *order, rt_scene_info *info, rt_bvh_stats *stats);
+
+/* The same builder run on the GPU of `ctx`, breadth first: one pass per tree level over all triangles
+ * instead of one recursion per node (no counterpart in the reference, whose builder recurses on the CPU
+ * with rayon::join, src/bvh/build.rs:174-193).  The same nodes, boxes, leaf ranges and BvhStats as
+ * rt_bvh_build_search_host; nodes are numbered breadth first instead of in pre-order and the
+ * triangles inside a leaf may come in another order.  rt_scene_create uses it for meshes of 2^18
+ * triangles and more (option "fast_tree_device_build") while the host threads build the reference's
+ * tree, and falls back to the host builder when the GPU build cannot run (RT_ERR_HIP here). */
+int rt_bvh_build_search_device(rt_ctx *ctx, const float *positions, uint32_t num_vertices, const uint32_t *indices,
+                               uint32_t num_triangles, uint32_t buckets, uint32_t max_leaf, rt_flat_node *nodes,
+                               uint32_t *order, rt_scene_info *info, rt_bvh_stats *stats);
+/* Box of all vertices of the scene's mesh (no counterpart in the reference; the library scales the
+ * Morton keys of its ray-queue sorts with it). */
+int rt_scene_bounds(const rt_scene *scene, float lo[3], float hi[3]);
+/* *out = 1 when the scene's fast-form tree came from the device-side builder, 0 when from the host's */
+int rt_scene_fast_tree_on_device(const rt_scene *scene, int *out);
 
 /* 4-wide traversal form of the tree (no counterpart in the reference, whose tree
  * is binary, src/bvh.rs:19-34).

@@ -129,6 +129,10 @@ EXPORTS = {
     "rt_scene_destroy": (None, [_vp]),
     "rt_bvh_build_search_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp,
                                            C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
+    "rt_bvh_build_search_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp,
+                                             C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
+    "rt_scene_fast_tree_on_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "rt_scene_bounds": (C.c_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
     "rt_bvh_build_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
                                     C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
     "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
@@ -227,6 +231,21 @@ def build_bvh_search_host(positions, indices, buckets=32, max_leaf=3, threads=0)
     info, st = SceneInfo(), BvhStats()
     _check(_lib.rt_bvh_build_search_host(_p(pos), pos.shape[0], _p(idx), nt, int(threads), int(buckets), int(max_leaf),
                                          _p(nodes), _p(order), C.byref(info), C.byref(st)))
+    inf = {n: int(getattr(info, n)) for n, _ in SceneInfo._fields_}
+    return nodes[:inf["num_inner_nodes"]].copy(), order, inf, st.as_dict()
+
+
+def build_bvh_search_device(ctx, positions, indices, buckets=32, max_leaf=3):
+    """rt_bvh_build_search_device: the search builder run on the GPU of `ctx`; same returns as
+    build_bvh_search_host (nodes numbered breadth first)."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    nt = idx.shape[0]
+    nodes = np.zeros(nt, dtype=NODE_DTYPE)
+    order = np.zeros(nt, dtype=np.uint32)
+    info, st = SceneInfo(), BvhStats()
+    _check(_lib.rt_bvh_build_search_device(ctx.h, _p(pos), pos.shape[0], _p(idx), nt, int(buckets), int(max_leaf),
+                                           _p(nodes), _p(order), C.byref(info), C.byref(st)))
     inf = {n: int(getattr(info, n)) for n, _ in SceneInfo._fields_}
     return nodes[:inf["num_inner_nodes"]].copy(), order, inf, st.as_dict()
 
@@ -406,6 +425,18 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    def bounds(self):
+        """(lo, hi) of the mesh's vertices."""
+        lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
+        _check(_lib.rt_scene_bounds(self.h, C.byref(lo), C.byref(hi)))
+        return np.array(lo[:], np.float32), np.array(hi[:], np.float32)
+
+    def fast_tree_on_device(self):
+        """True when the tree of the fast traversal forms came from the device-side builder."""
+        out = C.c_int(0)
+        _check(_lib.rt_scene_fast_tree_on_device(self.h, C.byref(out)))
+        return bool(out.value)
 
     def bvh_stats(self):
         st = BvhStats()

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <exception>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -23,6 +24,7 @@
 
 #include "../../include/rtcore.h"
 #include "bvh_build.hpp"
+#include "bvh_build_gpu.hpp"
 #include "wide_bvh.hpp"
 #include "device_layout.h"
 #include "kernels.h"
@@ -137,6 +139,7 @@ struct rt_ctx {
     unsigned min_active[2][2] = {{20, 20}, {40, 40}};
     // traversal loop form (TraceLaunch::mode): [0] for depth-0 launches (coherent rays: the
     // while-while form wins), [1] for deeper launches and the stream entry points
+    unsigned fast_tree_device_build = 1; // the fast forms' tree is built on the GPU: 0 never, 1 from 2^18 triangles, 2 always
     unsigned fast_tree_buckets = 32; // >= 2: the fast forms get a tree from the search builder with that many buckets; 0: the reference's tree
     // most triangles in a leaf of the fast forms' tree (1..3): 2 against 3 is +2 % on San-Miguel-class, +1 % on
     // dragon-class, nothing on Sponza-class; 1 gains on the deep launches and loses more on the depth-0 ones
@@ -194,10 +197,12 @@ struct rt_scene {
     DevBuf nodes, witems, tris, big, normals;
     uint32_t num_wide_nodes = 0;
     uint32_t num_wide_units = 0; // 16-byte units of the wide tree's item array
+    bool fast_tree_on_device = false; // the search tree came from the device-side builder
     uint32_t stack_bound = 0; // entries a lane's traversal stack can need on this scene
     SceneDev dev{};
     uint64_t device_bytes = 0;
     float bounds_lo[3] = {0, 0, 0};
+    float bounds_hi[3] = {0, 0, 0};
     float key_scale[3] = {0, 0, 0}; // 1024 / extent, for the Morton sort keys
 };
 
@@ -452,6 +457,8 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->fuse_primary = (unsigned)value;
     } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
         ctx->fast_tree_buckets = (unsigned)value;
+    } else if (n == "fast_tree_device_build" && in(0, 2)) {
+        ctx->fast_tree_device_build = (unsigned)value;
     } else if (n == "fast_tree_max_leaf" && in(1, kWideLeafTris)) {
         ctx->fast_tree_max_leaf = (unsigned)value;
     } else if (n == "traversal_stream" && in(0, 7)) {
@@ -606,10 +613,60 @@ extern "C" int rt_ctx_last_max_stack_entries(rt_ctx *ctx, uint64_t out[2])
 // A NaN or infinite coordinate makes every binning decision of the builder meaningless (the
 // reference would index outside its bucket array and panic, src/bvh/build.rs:118-120); meshes are
 // checked once here.  Returns the index of the first such float, or -1.
+// fn(begin, end) over [0, n) cut into slices for up to 16 threads (scans of large meshes); threads that were
+// started are joined whatever happens
+template <class F>
+static void scan_slices(size_t n, F fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = n < (1u << 20) ? 1u : std::min(16u, std::max(1u, hw));
+    if (T == 1) {
+        fn((size_t)0, n, 0u);
+        return;
+    }
+    struct Pool {
+        std::vector<std::thread> threads;
+        ~Pool()
+        {
+            for (auto &th : threads)
+                if (th.joinable()) th.join();
+        }
+    } pool;
+    pool.threads.reserve(T);
+    for (unsigned t = 1; t < T; t++) pool.threads.emplace_back([&fn, n, t, T] { fn(n * t / T, n * (t + 1) / T, t); });
+    fn((size_t)0, n / T, 0u);
+}
+
 static long long first_non_finite(const float *positions, uint32_t num_vertices)
 {
-    for (size_t i = 0; i < (size_t)num_vertices * 3; i++)
-        if (!std::isfinite(positions[i])) return (long long)i;
+    long long first[16];
+    for (long long &f : first) f = -1;
+    scan_slices((size_t)num_vertices * 3, [&](size_t lo, size_t hi, unsigned t) {
+        for (size_t i = lo; i < hi; i++)
+            if (!std::isfinite(positions[i])) {
+                first[t] = (long long)i;
+                return;
+            }
+    });
+    for (long long f : first)
+        if (f >= 0) return f; // slices are in index order: the first hit of the first slice that has one
+    return -1;
+}
+
+// index of the first entry of `indices` that is not below num_vertices, or -1
+static long long first_bad_index(const uint32_t *indices, size_t count, uint32_t num_vertices)
+{
+    long long first[16];
+    for (long long &f : first) f = -1;
+    scan_slices(count, [&](size_t lo, size_t hi, unsigned t) {
+        for (size_t i = lo; i < hi; i++)
+            if (indices[i] >= num_vertices) {
+                first[t] = (long long)i;
+                return;
+            }
+    });
+    for (long long f : first)
+        if (f >= 0) return f;
     return -1;
 }
 
@@ -626,16 +683,45 @@ static uint32_t make_dev_nodes(const rt_flat_node *nodes, size_t nn, uint32_t ro
         return kLeafBit | kBigLeafBit | (uint32_t)(big.size() - 1);
     };
     dn.resize(nn);
-    for (size_t i = 0; i < nn; i++) {
-        const rt_flat_node &s = nodes[i];
-        DevNode &d = dn[i];
-        memcpy(d.bx, s.bx, sizeof d.bx);
-        memcpy(d.by, s.by, sizeof d.by);
-        memcpy(d.bz, s.bz, sizeof d.bz);
-        d.left = pack_ref(s.left, s.left_count);
-        d.right = pack_ref(s.right, s.right_count);
-        d.pad0 = d.pad1 = 0;
+    // leaves of more than 8 triangles (coincident centroids) are rare and numbered in node order: the
+    // nodes are converted in parallel with those references left open, then the few are filled in
+    auto is_big = [](uint32_t ref, uint32_t count) { return (ref & kLeafBit) && !(count >= 1 && count <= 8); };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = nn < (1u << 18) ? 1u : std::min(16u, std::max(1u, hw));
+    std::vector<std::vector<uint32_t>> open(T); // nodes with a big-leaf child, per thread in index order
+    {
+        struct Pool {
+            std::vector<std::thread> threads;
+            ~Pool()
+            {
+                for (auto &th : threads)
+                    if (th.joinable()) th.join();
+            }
+        } pool;
+        auto work = [&](unsigned t) {
+            for (size_t i = nn * t / T; i < nn * (t + 1) / T; i++) {
+                const rt_flat_node &s = nodes[i];
+                DevNode &d = dn[i];
+                memcpy(d.bx, s.bx, sizeof d.bx);
+                memcpy(d.by, s.by, sizeof d.by);
+                memcpy(d.bz, s.bz, sizeof d.bz);
+                const bool bl = is_big(s.left, s.left_count), br = is_big(s.right, s.right_count);
+                d.left = bl ? 0u : (s.left & kLeafBit) ? kLeafBit | ((s.left & 0x7FFFFFFFu) << 3) | (s.left_count - 1) : s.left;
+                d.right = br ? 0u : (s.right & kLeafBit) ? kLeafBit | ((s.right & 0x7FFFFFFFu) << 3) | (s.right_count - 1) : s.right;
+                d.pad0 = d.pad1 = 0;
+                if (bl || br) open[t].push_back((uint32_t)i);
+            }
+        };
+        pool.threads.reserve(T);
+        for (unsigned t = 1; t < T; t++) pool.threads.emplace_back(work, t);
+        work(0);
     }
+    for (unsigned t = 0; t < T; t++)
+        for (uint32_t i : open[t]) {
+            const rt_flat_node &s = nodes[i];
+            if (is_big(s.left, s.left_count)) dn[i].left = pack_ref(s.left, s.left_count);
+            if (is_big(s.right, s.right_count)) dn[i].right = pack_ref(s.right, s.right_count);
+        }
     return pack_ref(root_ref, root_count);
 }
 
@@ -654,10 +740,9 @@ extern "C" int rt_scene_create(rt_ctx *ctx, const float *positions, uint32_t num
         return fail(RT_ERR_INVALID, "rt_scene_create: empty mesh");
     if (num_triangles >= kMaxPackedFirst)
         return fail(RT_ERR_LIMIT, "rt_scene_create: %u triangles, limit is %u", num_triangles, kMaxPackedFirst - 1);
-    for (size_t i = 0; i < (size_t)num_triangles * 3; i++)
-        if (indices[i] >= num_vertices)
-            return fail(RT_ERR_INVALID, "rt_scene_create: index %u at %zu out of range (%u vertices)", indices[i],
-                        i, num_vertices);
+    if (const long long i = first_bad_index(indices, (size_t)num_triangles * 3, num_vertices); i >= 0)
+        return fail(RT_ERR_INVALID, "rt_scene_create: index %u at %lld out of range (%u vertices)", indices[i], i,
+                    num_vertices);
     if (const long long bad = first_non_finite(positions, num_vertices); bad >= 0)
         return fail(RT_ERR_INVALID, "rt_scene_create: vertex %lld has a NaN or infinite coordinate", bad / 3);
     int rc = ctx_set_device(ctx);
@@ -717,35 +802,6 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         const int v = atoi(env);
         if (v == 0 || (v >= 2 && v <= 64)) search_buckets = (unsigned)v;
     }
-    // The fast forms walk a tree of their own: same builder family, wider search (bvh_build.hpp).  It does
-    // not depend on the reference's tree, so the two are built side by side (both builders run their
-    // upper levels on few threads).
-    HostBvh hs;
-    std::exception_ptr search_error;
-    std::thread search_thread;
-    struct Joiner {
-        std::thread &t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } joiner{search_thread};
-    if (search_buckets >= 2)
-        search_thread = std::thread([&] {
-            try {
-                const BuildTuning tune{search_buckets, leaf_tris};
-                build_bvh(positions, num_vertices, indices, num_triangles, threads, hs, &tune);
-            } catch (...) {
-                search_error = std::current_exception();
-            }
-        });
-    build_bvh(positions, num_vertices, indices, num_triangles, threads, sc->host);
-    phase("reference tree");
-    const HostBvh &hb = sc->host;
-    if (hb.stats.max_depth > 1024)
-        return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth %u beyond the supported 1024", hb.stats.max_depth);
-
-    // device images
-    std::vector<BigLeaf> big;
-    std::vector<DevNode> dn;
-    const uint32_t root = make_dev_nodes(hb.nodes.data(), hb.nodes.size(), hb.root_ref, hb.root_count, dn, big);
     // fn(begin, end) over [0, n) on the build threads (plain loops over millions of triangles)
     auto parallel_ranges = [&](size_t n, auto fn) {
         const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 65536 + 1));
@@ -766,8 +822,10 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         pool.threads.reserve(T);
         for (unsigned t = 0; t < T; t++) pool.threads.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
     };
-    auto make_tris = [&](const std::vector<uint32_t> &order, std::vector<DevTri> &dt) {
-        dt.resize(num_triangles);
+    // the large arrays below are written in full by the build threads: allocated without the
+    // single-threaded zero fill a std::vector would do first
+    auto make_tris = [&](const std::vector<uint32_t> &order, std::unique_ptr<DevTri[]> &dt) {
+        dt.reset(new DevTri[num_triangles]);
         parallel_ranges(num_triangles, [&](size_t lo, size_t hi) {
             for (size_t slot = lo; slot < hi; slot++) {
                 uint32_t t = order[slot];
@@ -785,37 +843,135 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
             }
         });
     };
-    std::vector<DevTri> dt;
-    make_tris(hb.order, dt);
-    phase("device nodes + triangles");
-    std::vector<DevNode> xdn;
-    std::vector<uint32_t> xorder;
-    uint32_t xroot = root;
-    uint32_t extra_depth = 0, fast_depth = hb.stats.max_depth;
-    if (search_buckets >= 2) {
-        search_thread.join();
-        if (search_error) std::rethrow_exception(search_error);
-        phase("search tree (rest)");
-        std::vector<DevNode> sdn;
+
+    // Two pipelines that share nothing but the mesh.  The reference's tree (what the exact forms walk):
+    // build, device nodes, triangles in its leaf order, normals.  The fast forms' tree: the search
+    // builder's tree (bvh_build.hpp: same builder family, wider search) -- made on the GPU, breadth first
+    // (bvh_build_gpu.hip), for meshes where that matters, else on the host -- then leaves refined, 4-wide
+    // collapse, layout, quantization, packing.  They run side by side on the host threads; with
+    // fast_tree_buckets = 0 the second starts from the first one's tree and follows it.
+    const HostBvh &hb = sc->host;
+    std::vector<BigLeaf> big;
+    std::vector<DevNode> dn;
+    std::unique_ptr<DevTri[]> dt;
+    std::unique_ptr<float[]> n4;
+    uint32_t root = 0;
+    auto reference_pipeline = [&] {
+        build_bvh(positions, num_vertices, indices, num_triangles, threads, sc->host);
+        root = make_dev_nodes(hb.nodes.data(), hb.nodes.size(), hb.root_ref, hb.root_count, dn, big);
+        make_tris(hb.order, dt);
+        n4.reset(new float[(size_t)num_triangles * 4]);
+        parallel_ranges(num_triangles, [&](size_t lo, size_t hi) {
+            for (size_t t = lo; t < hi; t++) {
+                n4[4 * t + 0] = geom_normals[3 * t + 0];
+                n4[4 * t + 1] = geom_normals[3 * t + 1];
+                n4[4 * t + 2] = geom_normals[3 * t + 2];
+                n4[4 * t + 3] = 0.f;
+            }
+        });
+    };
+    HostBvh hs;
+    std::unique_ptr<Unit[]> items;
+    size_t num_items = 0;
+    WideLayout layout;
+    uint32_t wide_depth = 0, extra_depth = 0, fast_depth = 0;
+    int fast_error = 0; // 1: a leaf too large for the wide tree, 2: too many units (reported on the calling thread)
+    unsigned align_mode = 0;
+    if (const char *env = getenv("RTCORE_WIDE_ALIGN")) align_mode = (unsigned)atoi(env);
+    // from a binary tree (search tree, or the reference's with fast_tree_buckets = 0) to the packed items
+    auto fast_pipeline = [&](const rt_flat_node *nodes, size_t num_nodes, uint32_t root_ref, uint32_t root_count,
+                             const std::vector<uint32_t> &order, uint32_t depth, uint32_t max_objs) {
+        std::vector<DevNode> sdn, xdn;
         std::vector<BigLeaf> sbig;
-        const uint32_t sroot = make_dev_nodes(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, sdn, sbig);
-        extra_depth = refine_leaves(sdn, sroot, positions, indices, hs.order, leaf_tris, sbig, xdn, xroot, xorder);
-        fast_depth = hs.stats.max_depth;
-    } else {
-        extra_depth = refine_leaves(dn, root, positions, indices, hb.order, leaf_tris, big, xdn, xroot, xorder);
-    }
-    phase("refined leaves");
-    std::vector<DevTri> xdt;
-    make_tris(xorder, xdt);
-    std::vector<float> n4((size_t)num_triangles * 4);
-    parallel_ranges(num_triangles, [&](size_t lo, size_t hi) {
-        for (size_t t = lo; t < hi; t++) {
-            n4[4 * t + 0] = geom_normals[3 * t + 0];
-            n4[4 * t + 1] = geom_normals[3 * t + 1];
-            n4[4 * t + 2] = geom_normals[3 * t + 2];
-            n4[4 * t + 3] = 0.f;
+        std::vector<uint32_t> xorder;
+        uint32_t xroot = 0;
+        const uint32_t sroot = make_dev_nodes(nodes, num_nodes, root_ref, root_count, sdn, sbig);
+        phase("  device nodes");
+        if (max_objs <= leaf_tris) { // no leaf to split: the tree and its order are used as they are
+            xdn.swap(sdn);
+            xroot = sroot;
+            extra_depth = 0;
+        } else {
+            extra_depth = refine_leaves(sdn, sroot, positions, indices, order, leaf_tris, sbig, xdn, xroot, xorder);
         }
-    });
+        const std::vector<uint32_t> &final_order = max_objs <= leaf_tris ? order : xorder;
+        fast_depth = depth;
+        phase("  refined leaves");
+        std::unique_ptr<DevTri[]> xdt;
+        make_tris(final_order, xdt);
+        phase("  wide-order triangles");
+        std::vector<DevWideNode> wn;
+        const uint32_t wroot = collapse_wide4(xdn.data(), xdn.size(), xroot, wn, &wide_depth);
+        phase("  4-wide collapse");
+        sc->num_wide_nodes = (uint32_t)wn.size();
+        if (!layout_wide4(wn, wroot, num_triangles, layout, align_mode)) {
+            fast_error = 1;
+            return;
+        }
+        phase("  layout");
+        if (layout.num_units >= (1u << 30)) {
+            fast_error = 2;
+            return;
+        }
+        num_items = (size_t)layout.num_units + 1;
+        items.reset(new Unit[num_items]);
+        pack_wide4(wn, layout, xdt.get(), num_triangles, items.get(), false);
+        sc->num_wide_units = (uint32_t)num_items;
+        phase("  quantize + pack");
+    };
+    unsigned device_build = ctx->fast_tree_device_build;
+    if (const char *env = getenv("RTCORE_FAST_TREE_DEVICE_BUILD")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 2) device_build = (unsigned)v;
+    }
+    const bool on_device = search_buckets >= 2 && (device_build == 2 || (device_build == 1 && num_triangles >= (1u << 18)));
+    sc->fast_tree_on_device = false;
+    if (search_buckets >= 2) {
+        // the reference pipeline on a thread of its own, the fast one here (the GPU build needs this
+        // thread's device)
+        std::exception_ptr ref_error;
+        std::thread ref_thread([&] {
+            try {
+                reference_pipeline();
+            } catch (...) {
+                ref_error = std::current_exception();
+            }
+        });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } ref_joiner{ref_thread};
+        const BuildTuning tune{search_buckets, leaf_tris};
+        if (on_device) {
+            std::string why;
+            sc->fast_tree_on_device = build_bvh_search_device(positions, num_vertices, indices, num_triangles, tune, hs, why);
+            phase("search tree (device)");
+            if (!sc->fast_tree_on_device && verbose)
+                fprintf(stderr, "rt_scene_create: device build not used: %s\n", why.c_str());
+        }
+        if (!sc->fast_tree_on_device) {
+            build_bvh(positions, num_vertices, indices, num_triangles, threads, hs, &tune);
+            phase("search tree (host)");
+        }
+        fast_pipeline(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, hs.order, hs.stats.max_depth,
+                      hs.stats.max_objs);
+        phase("refine, collapse, layout, pack");
+        ref_thread.join();
+        if (ref_error) std::rethrow_exception(ref_error);
+        phase("reference pipeline (rest)");
+    } else {
+        reference_pipeline();
+        phase("reference pipeline");
+        fast_pipeline(hb.nodes.data(), hb.nodes.size(), hb.root_ref, hb.root_count, hb.order, hb.stats.max_depth,
+                      hb.stats.max_objs);
+        phase("refine, collapse, layout, pack");
+    }
+    if (hb.stats.max_depth > 1024)
+        return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth %u beyond the supported 1024", hb.stats.max_depth);
+    if (fast_error == 1)
+        return fail(RT_ERR_LIMIT, "rt_scene_create: the wide tree has a leaf of more than %u triangles", kWideLeafTris);
+    if (fast_error == 2)
+        return fail(RT_ERR_LIMIT, "rt_scene_create: %u units in the wide tree, limit is 2^30", layout.num_units);
 
     auto upload = [&](DevBuf &buf, const void *src, size_t bytes) -> int {
         int r = buf.ensure(bytes ? bytes : 16);
@@ -824,28 +980,11 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         sc->device_bytes += bytes;
         return RT_OK;
     };
-    phase("wide-order triangles, normals");
-    std::vector<DevWideNode> wn;
-    uint32_t wide_depth = 0;
-    const uint32_t wroot = collapse_wide4(xdn.data(), xdn.size(), xroot, wn, &wide_depth);
-    phase("4-wide collapse");
-    sc->num_wide_nodes = (uint32_t)wn.size();
-    WideLayout layout;
-    unsigned align_mode = 0;
-    if (const char *env = getenv("RTCORE_WIDE_ALIGN")) align_mode = (unsigned)atoi(env);
-    if (!layout_wide4(wn, wroot, num_triangles, layout, align_mode))
-        return fail(RT_ERR_LIMIT, "rt_scene_create: the wide tree has a leaf of more than %u triangles", kWideLeafTris);
-    if (layout.num_units >= (1u << 30))
-        return fail(RT_ERR_LIMIT, "rt_scene_create: %u units in the wide tree, limit is 2^30", layout.num_units);
-    std::vector<Unit> items;
-    pack_wide4(wn, layout, xdt.data(), num_triangles, items);
-    sc->num_wide_units = (uint32_t)items.size();
-    phase("layout + quantize + pack");
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
-    if (rc == RT_OK) rc = upload(sc->witems, items.data(), items.size() * sizeof(Unit));
-    if (rc == RT_OK) rc = upload(sc->tris, dt.data(), dt.size() * sizeof(DevTri));
+    if (rc == RT_OK) rc = upload(sc->witems, items.get(), num_items * sizeof(Unit));
+    if (rc == RT_OK) rc = upload(sc->tris, dt.get(), (size_t)num_triangles * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
-    if (rc == RT_OK) rc = upload(sc->normals, n4.data(), n4.size() * sizeof(float));
+    if (rc == RT_OK) rc = upload(sc->normals, n4.get(), (size_t)num_triangles * 4 * sizeof(float));
     phase("uploads");
     // Deepest traversal stack of a lane.  Binary walk: one deferred sibling per level.
     // Wide walk: up to three deferred children per wide level.
@@ -854,17 +993,38 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     if (rc != RT_OK) return rc;
     {
         float lo[3] = {positions[0], positions[1], positions[2]}, hi[3] = {positions[0], positions[1], positions[2]};
-        for (uint32_t v = 1; v < num_vertices; v++)
+        float part[16][6];
+        for (auto &p : part)
             for (int k = 0; k < 3; k++) {
-                float x = positions[3 * (size_t)v + k];
-                lo[k] = std::min(lo[k], x);
-                hi[k] = std::max(hi[k], x);
+                p[k] = positions[k];
+                p[3 + k] = positions[k];
+            }
+        scan_slices(num_vertices, [&](size_t v0, size_t v1, unsigned t) {
+            float l[3] = {positions[0], positions[1], positions[2]}, h[3] = {positions[0], positions[1], positions[2]};
+            for (size_t v = v0; v < v1; v++)
+                for (int k = 0; k < 3; k++) {
+                    const float x = positions[3 * v + k];
+                    l[k] = std::min(l[k], x);
+                    h[k] = std::max(h[k], x);
+                }
+            for (int k = 0; k < 3; k++) {
+                part[t][k] = l[k];
+                part[t][3 + k] = h[k];
+            }
+        });
+        for (auto &p : part)
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(lo[k], p[k]);
+                hi[k] = std::max(hi[k], p[3 + k]);
             }
         for (int k = 0; k < 3; k++) {
             float ext = hi[k] - lo[k];
             sc->bounds_lo[k] = lo[k];
+            sc->bounds_hi[k] = hi[k];
             sc->key_scale[k] = ext > 0.f ? 1024.f / ext : 0.f;
         }
+        if (verbose)
+            fprintf(stderr, "rt_scene_create: bounds (%g %g %g) .. (%g %g %g)\n", lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
     }
     sc->dev.nodes = (const DevNode *)sc->nodes.p;
     sc->dev.tris = (const DevTri *)sc->tris.p;
@@ -921,6 +1081,61 @@ extern "C" int rt_bvh_build_host(const float *positions, uint32_t num_vertices, 
 {
     return bvh_build_host_impl("rt_bvh_build_host", positions, num_vertices, indices, num_triangles, threads, nullptr,
                                nodes, order, info, stats);
+}
+
+extern "C" int rt_scene_bounds(const rt_scene *sc, float lo[3], float hi[3])
+{
+    if (!sc || !lo || !hi) return fail(RT_ERR_INVALID, "rt_scene_bounds: NULL argument");
+    for (int k = 0; k < 3; k++) {
+        lo[k] = sc->bounds_lo[k];
+        hi[k] = sc->bounds_hi[k];
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_scene_fast_tree_on_device(const rt_scene *sc, int *out)
+{
+    if (!sc || !out) return fail(RT_ERR_INVALID, "rt_scene_fast_tree_on_device: NULL argument");
+    *out = sc->fast_tree_on_device ? 1 : 0;
+    return RT_OK;
+}
+
+extern "C" int rt_bvh_build_search_device(rt_ctx *ctx, const float *positions, uint32_t num_vertices,
+                                          const uint32_t *indices, uint32_t num_triangles, uint32_t buckets,
+                                          uint32_t max_leaf, rt_flat_node *nodes, uint32_t *order, rt_scene_info *info,
+                                          rt_bvh_stats *stats)
+{
+    if (!ctx || !positions || !indices || !nodes || !order)
+        return fail(RT_ERR_INVALID, "rt_bvh_build_search_device: NULL argument");
+    if (num_triangles == 0 || num_vertices == 0) return fail(RT_ERR_INVALID, "rt_bvh_build_search_device: empty mesh");
+    if (buckets < 2 || buckets > 64 || max_leaf < 1 || max_leaf > 8)
+        return fail(RT_ERR_INVALID, "rt_bvh_build_search_device: buckets 2..64, max_leaf 1..8");
+    for (size_t i = 0; i < (size_t)num_triangles * 3; i++)
+        if (indices[i] >= num_vertices)
+            return fail(RT_ERR_INVALID, "rt_bvh_build_search_device: index %u at %zu out of range", indices[i], i);
+    if (const long long bad = first_non_finite(positions, num_vertices); bad >= 0)
+        return fail(RT_ERR_INVALID, "rt_bvh_build_search_device: vertex %lld has a NaN or infinite coordinate", bad / 3);
+    int rc = ctx_set_device(ctx);
+    if (rc != RT_OK) return rc;
+    HostBvh hb;
+    std::string why;
+    try {
+        if (!build_bvh_search_device(positions, num_vertices, indices, num_triangles, BuildTuning{buckets, max_leaf}, hb, why))
+            return fail(RT_ERR_HIP, "rt_bvh_build_search_device: %s", why.c_str());
+    } catch (const std::exception &ex) {
+        return fail(RT_ERR_NOMEM, "rt_bvh_build_search_device: %s", ex.what());
+    }
+    if (!hb.nodes.empty()) memcpy(nodes, hb.nodes.data(), hb.nodes.size() * sizeof(rt_flat_node));
+    memcpy(order, hb.order.data(), hb.order.size() * sizeof(uint32_t));
+    if (info) {
+        info->num_triangles = num_triangles;
+        info->num_inner_nodes = (uint32_t)hb.nodes.size();
+        info->root_ref = hb.root_ref;
+        info->root_count = hb.root_count;
+        info->device_bytes = 0;
+    }
+    if (stats) *stats = hb.stats;
+    return RT_OK;
 }
 
 extern "C" int rt_bvh_build_search_host(const float *positions, uint32_t num_vertices, const uint32_t *indices,

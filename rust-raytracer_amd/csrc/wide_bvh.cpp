@@ -1,6 +1,7 @@
 #include "wide_bvh.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -44,71 +45,6 @@ struct Pending {
 
 } // namespace
 
-uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, std::vector<DevWideNode> &out,
-                        uint32_t *max_wide_depth)
-{
-    if (max_wide_depth) *max_wide_depth = 0;
-    if ((root_ref & kLeafBit) || num_nodes == 0) return root_ref;
-    const float inf = std::numeric_limits<float>::infinity();
-    out.reserve(out.size() + num_nodes / 2 + 1);
-    const uint32_t root_index = (uint32_t)out.size();
-    std::vector<Pending> todo;
-    todo.push_back(Pending{root_ref, 0xFFFFFFFFu, 0, 1});
-    uint32_t deepest = 0;
-    while (!todo.empty()) {
-        const Pending job = todo.back();
-        todo.pop_back();
-        const uint32_t self = (uint32_t)out.size();
-        out.emplace_back();
-        if (job.parent != 0xFFFFFFFFu) out[job.parent].child[job.slot] = self;
-        if (job.depth > deepest) deepest = job.depth;
-
-        Slot c[4];
-        int n = 2;
-        children_of(bn[job.bin], c[0], c[1]);
-        while (n < 4) {
-            int pick = -1;
-            float best = -1.f;
-            for (int i = 0; i < n; i++) {
-                if (c[i].ref & kLeafBit) continue;
-                const float a = c[i].area();
-                if (pick < 0 || a > best) {
-                    pick = i;
-                    best = a;
-                }
-            }
-            if (pick < 0) break;
-            // the two children take the place of the opened child
-            for (int i = n - 1; i > pick; i--) c[i + 1] = c[i];
-            const uint32_t opened = c[pick].ref;
-            children_of(bn[opened], c[pick], c[pick + 1]);
-            n++;
-        }
-
-        // Slot order is the order the any-hit walk visits hit children in.  Left to right (the
-        // binary tree's order, which follows the split axis whatever the ray's direction) measured
-        // 3-20 % slower there than any order by box size; largest first is the one kept.  The
-        // closest-hit walk orders by entry distance and only falls back to slots on ties.
-        std::stable_sort(c, c + n, [](const Slot &a, const Slot &b) { return a.area() > b.area(); });
-        DevWideNode &w = out[self];
-        for (int i = 0; i < 4; i++) {
-            const bool used = i < n;
-            for (int k = 0; k < 3; k++) {
-                w.lo[k][i] = used ? c[i].lo[k] : inf;
-                w.hi[k][i] = used ? c[i].hi[k] : -inf;
-            }
-            w.child[i] = used ? c[i].ref : c[0].ref; // n < 4 only when every child is a leaf
-        }
-        w.bin = job.bin;
-        w.pad[0] = w.pad[1] = w.pad[2] = 0;
-        // inner children become wide nodes; the first one is numbered next (pre-order)
-        for (int i = n - 1; i >= 0; i--)
-            if (!(c[i].ref & kLeafBit)) todo.push_back(Pending{c[i].ref, self, (uint32_t)i, job.depth + 1});
-    }
-    if (max_wide_depth) *max_wide_depth = deepest;
-    return root_index;
-}
-
 namespace {
 
 unsigned worker_threads()
@@ -120,11 +56,168 @@ unsigned worker_threads()
 template <class F>
 void run_parallel(unsigned n, F fn)
 {
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < n; t++) pool.emplace_back([&fn, t] { fn(t); });
+    // threads already started are joined whatever happens (a later one may fail to start)
+    struct Pool {
+        std::vector<std::thread> threads;
+        ~Pool()
+        {
+            for (auto &th : threads)
+                if (th.joinable()) th.join();
+        }
+    } pool;
+    pool.threads.reserve(n);
+    for (unsigned t = 1; t < n; t++) pool.threads.emplace_back([&fn, t] { fn(t); });
     fn(0);
-    for (auto &th : pool) th.join();
 }
+
+// The wide node over binary node `bin`: children of inner children are pulled up, largest surface
+// area first, until there are four; returns how many slots are used.
+int collapse_node(const DevNode *bn, uint32_t bin, DevWideNode &w, Slot (&c)[4])
+{
+    const float inf = std::numeric_limits<float>::infinity();
+    int n = 2;
+    children_of(bn[bin], c[0], c[1]);
+    while (n < 4) {
+        int pick = -1;
+        float best = -1.f;
+        for (int i = 0; i < n; i++) {
+            if (c[i].ref & kLeafBit) continue;
+            const float a = c[i].area();
+            if (pick < 0 || a > best) {
+                pick = i;
+                best = a;
+            }
+        }
+        if (pick < 0) break;
+        // the two children take the place of the opened child
+        for (int i = n - 1; i > pick; i--) c[i + 1] = c[i];
+        const uint32_t opened = c[pick].ref;
+        children_of(bn[opened], c[pick], c[pick + 1]);
+        n++;
+    }
+    // Slot order is the order the any-hit walk visits hit children in.  Left to right (the
+    // binary tree's order, which follows the split axis whatever the ray's direction) measured
+    // 3-20 % slower there than any order by box size; largest first is the one kept.  The
+    // closest-hit walk orders by entry distance and only falls back to slots on ties.
+    std::stable_sort(c, c + n, [](const Slot &a, const Slot &b) { return a.area() > b.area(); });
+    for (int i = 0; i < 4; i++) {
+        const bool used = i < n;
+        for (int k = 0; k < 3; k++) {
+            w.lo[k][i] = used ? c[i].lo[k] : inf;
+            w.hi[k][i] = used ? c[i].hi[k] : -inf;
+        }
+        w.child[i] = used ? c[i].ref : c[0].ref; // n < 4 only when every child is a leaf
+    }
+    w.bin = bin;
+    w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    return n;
+}
+
+// Collapses the subtree under `first` into `out` (indices local to `out`, the subtree's root at 0
+// when out is empty); returns the deepest level reached (the first node's level being first.depth).
+uint32_t collapse_subtree(const DevNode *bn, Pending first, std::vector<DevWideNode> &out)
+{
+    std::vector<Pending> todo{first};
+    uint32_t deepest = 0;
+    while (!todo.empty()) {
+        const Pending job = todo.back();
+        todo.pop_back();
+        const uint32_t self = (uint32_t)out.size();
+        out.emplace_back();
+        if (job.parent != 0xFFFFFFFFu) out[job.parent].child[job.slot] = self;
+        if (job.depth > deepest) deepest = job.depth;
+        Slot c[4];
+        const int n = collapse_node(bn, job.bin, out[self], c);
+        // inner children become wide nodes; the first one is numbered next (pre-order)
+        for (int i = n - 1; i >= 0; i--)
+            if (!(c[i].ref & kLeafBit)) todo.push_back(Pending{c[i].ref, self, (uint32_t)i, job.depth + 1});
+    }
+    return deepest;
+}
+
+} // namespace
+
+// The upper levels are collapsed breadth first on the calling thread until there are enough open
+// subtrees for every worker; the subtrees are collapsed in parallel into vectors of their own and
+// appended.  Wide-node indices therefore follow no particular order (layout_wide4 follows the
+// child references from the root).
+uint32_t collapse_wide4(const DevNode *bn, size_t num_nodes, uint32_t root_ref, std::vector<DevWideNode> &out,
+                        uint32_t *max_wide_depth)
+{
+    if (max_wide_depth) *max_wide_depth = 0;
+    if ((root_ref & kLeafBit) || num_nodes == 0) return root_ref;
+    out.reserve(out.size() + num_nodes / 2 + 1);
+    const uint32_t root_index = (uint32_t)out.size();
+    const unsigned T = num_nodes < 65536 ? 1u : worker_threads();
+    uint32_t deepest = 0;
+    std::vector<Pending> open{Pending{root_ref, 0xFFFFFFFFu, 0, 1}};
+    if (T > 1) {
+        size_t head = 0;
+        while (head < open.size() && open.size() - head < 16u * T) {
+            const Pending job = open[head++];
+            const uint32_t self = (uint32_t)out.size();
+            out.emplace_back();
+            if (job.parent != 0xFFFFFFFFu) out[job.parent].child[job.slot] = self;
+            if (job.depth > deepest) deepest = job.depth;
+            Slot c[4];
+            const int n = collapse_node(bn, job.bin, out[self], c);
+            for (int i = 0; i < n; i++)
+                if (!(c[i].ref & kLeafBit)) open.push_back(Pending{c[i].ref, self, (uint32_t)i, job.depth + 1});
+        }
+        open.erase(open.begin(), open.begin() + (std::ptrdiff_t)head);
+    }
+    if (T == 1 || open.size() < 2) {
+        for (const Pending &job : open) { // parents are in `out` already: indices are global
+            const uint32_t self = (uint32_t)out.size();
+            const Pending local{job.bin, 0xFFFFFFFFu, 0, job.depth};
+            std::vector<DevWideNode> sub;
+            deepest = std::max(deepest, collapse_subtree(bn, local, sub));
+            for (DevWideNode w : sub) {
+                for (int i = 0; i < 4; i++)
+                    if (!(w.child[i] & kLeafBit)) w.child[i] += self;
+                out.push_back(w);
+            }
+            if (job.parent != 0xFFFFFFFFu) out[job.parent].child[job.slot] = self;
+        }
+        if (max_wide_depth) *max_wide_depth = deepest;
+        return root_index;
+    }
+    std::vector<std::vector<DevWideNode>> sub(open.size());
+    std::vector<uint32_t> sub_deepest(open.size(), 0);
+    std::atomic<size_t> next{0};
+    run_parallel(T, [&](unsigned) {
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= open.size()) break;
+            sub_deepest[j] = collapse_subtree(bn, Pending{open[j].bin, 0xFFFFFFFFu, 0, open[j].depth}, sub[j]);
+        }
+    });
+    std::vector<size_t> base(open.size() + 1, out.size());
+    for (size_t j = 0; j < open.size(); j++) base[j + 1] = base[j] + sub[j].size();
+    out.resize(base[open.size()]);
+    next = 0;
+    run_parallel(T, [&](unsigned) {
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= open.size()) break;
+            const uint32_t b = (uint32_t)base[j];
+            for (size_t i = 0; i < sub[j].size(); i++) {
+                DevWideNode w = sub[j][i];
+                for (int k = 0; k < 4; k++)
+                    if (!(w.child[k] & kLeafBit)) w.child[k] += b;
+                out[b + i] = w;
+            }
+        }
+    });
+    for (size_t j = 0; j < open.size(); j++) {
+        out[open[j].parent].child[open[j].slot] = (uint32_t)base[j];
+        deepest = std::max(deepest, sub_deepest[j]);
+    }
+    if (max_wide_depth) *max_wide_depth = deepest;
+    return root_index;
+}
+
+namespace {
 
 struct Box3 {
     float lo[3], hi[3];
@@ -482,11 +575,27 @@ DevQNode quantize_node(const DevWideNode &src, const WideLayout &layout)
 void pack_wide4(const std::vector<DevWideNode> &wide, const WideLayout &layout, const DevTri *xtris,
                 uint32_t num_triangles, std::vector<Unit> &items)
 {
+    items.resize((size_t)layout.num_units + 1);
+    pack_wide4(wide, layout, xtris, num_triangles, items.data(), true);
+}
+
+void pack_wide4(const std::vector<DevWideNode> &wide, const WideLayout &layout, const DevTri *xtris,
+                uint32_t num_triangles, Unit *items, bool gaps_cleared)
+{
     static_assert(sizeof(DevQNode) == kUnitsPerItem * sizeof(Unit) && sizeof(DevTri) == kUnitsPerItem * sizeof(Unit),
                   "items are three units");
-    items.assign((size_t)layout.num_units + 1, Unit{});
-    const size_t nodes = wide.size();
+    const size_t nodes = wide.size(), units = (size_t)layout.num_units + 1;
     const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(worker_threads(), (nodes + num_triangles) / 65536 + 1));
+    // units no item covers (alignment gaps, the spare unit at the end) read as zeros
+    const bool dense = (size_t)kUnitsPerItem * (nodes + num_triangles) == (size_t)layout.num_units;
+    if (!gaps_cleared) {
+        if (dense)
+            items[units - 1] = Unit{};
+        else
+            run_parallel(T, [&](unsigned t) {
+                std::memset((void *)(items + units * t / T), 0, (units * (t + 1) / T - units * t / T) * sizeof(Unit));
+            });
+    }
     run_parallel(T, [&](unsigned t) {
         for (size_t w = nodes * t / T; w < nodes * (t + 1) / T; w++) {
             const DevQNode q = quantize_node(wide[w], layout);

@@ -67,6 +67,9 @@ DevQNode quantize_node(const DevWideNode &src, const WideLayout &layout);
 
 // The unified array: every node quantized, every triangle of `xtris` (leaf order of the wide
 // tree) copied to its units; one spare unit at the end (a wave-uniform item is read as 64 bytes).
+// the same into a caller's buffer of layout.num_units + 1 units (gaps_cleared: it is zero-filled already)
+void pack_wide4(const std::vector<DevWideNode> &wide, const WideLayout &layout, const DevTri *xtris,
+                uint32_t num_triangles, Unit *items, bool gaps_cleared);
 void pack_wide4(const std::vector<DevWideNode> &wide, const WideLayout &layout, const DevTri *xtris,
                 uint32_t num_triangles, std::vector<Unit> &items);
 
