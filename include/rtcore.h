@@ -170,7 +170,7 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       ties, no visit counters, and 1/d is bounded as in the reference's
  *                       packet rays (src/simd_ray.rs:46-47) so that axis-parallel rays are
  *                       culled properly.  Calls that ask for visit counters always run form
- *                       0 or 1.  "traversal_deep" and "traversal_stream" also take three
+ *                       0 or 1.  "traversal_deep" and "traversal_stream" also take four
  *                       experimental variants of form 2 with the same results (kept for
  *                       measurements, none is faster): 5 = two rays per lane, the loads of
  *                       one issued behind the arithmetic of the other; 6 = a lane walks
@@ -178,7 +178,9 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       side, one node and one triangle per iteration; 7 = lanes only walk
  *                       nodes and the triangles of the leaves they reach go through a job
  *                       queue of the wave, tested 64 at a time by whichever lanes are free
- *                       (of triangles at exactly the same distance the lowest id wins).
+ *                       (of triangles at exactly the same distance the lowest id wins); 8 = an
+ *                       iteration at a leaf loads its two triangles together with the item that
+ *                       follows the leaf (same visits in the same order as form 2: same ids too).
  *                       rt_intersect_stream_noalloc runs form 2 where 5 or 7 is selected.
  *   "traversal_deep_connect" form of the deeper any-hit launches of rt_render alone
  *                       (same values as "traversal_deep"; -1, the default, follows it)
@@ -195,9 +197,16 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       same either way (rt_bvh_build_search_device).
  *   "fast_tree_max_leaf" 1..3 (default 2), read by rt_scene_create: most triangles in a leaf of
  *                       the tree of forms 2 and 3
+ *   "fast_tree_align"   0, 1, 3 or 4 (default 4), read by rt_scene_create: placement of the 48-byte items of
+ *                       that tree against 128-byte cache lines.  0 = back to back; 1 = nodes on 64-byte
+ *                       boundaries; 3 = no item lies across a line (gaps only where one would); 4 = as 3, and a
+ *                       leaf of one or two triangles lies within one line (6 % more memory, 18 % fewer L1
+ *                       fills on incoherent rays).  Same tree, same results.
  *   "sort_extend_from", "sort_connect_from" first depth whose queue is Morton-ordered
  *                       (defaults: never = 0xFFFFFFFF for the bounce rays, 1 for the shadow rays)
  *   "sort_bits"         3..30 key bits that take part in the order
+ *   "sort_octant"       0/1 (default 0): bounce rays carry the octant of their direction in the three
+ *                       lowest ordered key bits
  *   "timing"            0/1 per-launch HIP events
  *   "overlap_connect"   0/1 (default 0): rt_render runs the any-hit launch of depth d on a stream of
  *                       the context's own beside the closest-hit launch of depth d + 1, so that the tail

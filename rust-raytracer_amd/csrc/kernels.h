@@ -78,6 +78,18 @@
 #ifndef RTC_TUNE_ANY6_LDS
 #define RTC_TUNE_ANY6_LDS 16
 #endif
+#ifndef RTC_TUNE_EXT8_WAVES
+#define RTC_TUNE_EXT8_WAVES 5
+#endif
+#ifndef RTC_TUNE_EXT8_LDS
+#define RTC_TUNE_EXT8_LDS RTC_LDS_STACK_DEPTH
+#endif
+#ifndef RTC_TUNE_ANY8_WAVES
+#define RTC_TUNE_ANY8_WAVES 6
+#endif
+#ifndef RTC_TUNE_ANY8_LDS
+#define RTC_TUNE_ANY8_LDS 16
+#endif
 #ifndef RTC_TUNE_EXT7_WAVES
 #define RTC_TUNE_EXT7_WAVES 6
 #endif
@@ -107,7 +119,7 @@
 #define RTC_MIN_LDS_STACK_DEPTH \
     RTC_MIN2_(RTC_MIN2_(RTC_MIN2_(RTC_LDS_STACK_DEPTH, RTC_TUNE_EXT2_LDS), RTC_TUNE_PRIMARY_LDS), \
               RTC_MIN2_(RTC_MIN2_(RTC_MIN2_(RTC_TUNE_ANY3_LDS, RTC_TUNE_ANY2_LDS), RTC_MIN2_(RTC_TUNE_EXT6_LDS, RTC_TUNE_ANY6_LDS)), \
-                        RTC_MIN2_(RTC_TUNE_EXT7_LDS, RTC_TUNE_ANY7_LDS)))
+                        RTC_MIN2_(RTC_MIN2_(RTC_TUNE_EXT7_LDS, RTC_TUNE_ANY7_LDS), RTC_MIN2_(RTC_TUNE_EXT8_LDS, RTC_TUNE_ANY8_LDS))))
 #else
 #define RTC_MIN_LDS_STACK_DEPTH RTC_LDS_STACK_DEPTH
 #endif
@@ -234,6 +246,8 @@ struct ShadeArgs {
     float key_lo[3];
     float key_scale[3]; // 1024 / extent per axis
     uint32_t key_mask;  // high bits of the 30-bit code that take part in the order
+    uint32_t key_dir_shift; // bounce rays: the direction's octant takes the three lowest ordered bits, at this
+                            // position (32: the key is the origin's code alone)
 };
 
 // sorts (key, index) pairs by bits [begin_bit, end_bit) of the key; indices are

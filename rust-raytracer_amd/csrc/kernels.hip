@@ -569,16 +569,103 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
 
 // The three 16-byte loads of one traversal item (a node or a triangle of the wide tree, 48 bytes)
 // as exactly three vector memory instructions, written out so that the compiler neither trims the
-// third load to the bytes one kind of item needs nor splits it: the instruction count is what the
-// kernel is bound by.
+// third load to the bytes one kind of item needs nor splits it: every instruction is a pass of its
+// lanes through the CU's address unit and L1 tag pipeline, the busiest units of these kernels.
+// RTC_PROBE_EXTRA_LOADS (measurement builds only): 1 or 2 more loads of the item's first 16 bytes, which hit
+// the line the first load brought in: more work for the address unit and the L1 tag pipeline, no more
+// misses.  (San-Miguel-class deep extend launch: +33 % L1 accesses, L1 pipeline 0.80 -> 0.985 accesses
+// per clock and CU, launch time +7 %.)
+#ifndef RTC_PROBE_EXTRA_LOADS
+#define RTC_PROBE_EXTRA_LOADS 0
+#endif
 __device__ __forceinline__ void load_item(const float4 *p, float4 &a0, float4 &a1, float4 &a2)
 {
+#if RTC_PROBE_EXTRA_LOADS
+    float4 x0, x1;
+    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off\n\t"
+#if RTC_PROBE_EXTRA_LOADS > 1
+                 "global_load_dwordx4 %4, %5, off offset:16\n\t"
+#endif
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(x0), "=&v"(x1)
+                 : "v"(p)
+                 : "memory");
+    return;
+#endif
     asm volatile("global_load_dwordx4 %0, %3, off\n\t"
                  "global_load_dwordx4 %1, %3, off offset:16\n\t"
                  "global_load_dwordx4 %2, %3, off offset:32\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1), "=&v"(a2)
                  : "v"(p)
+                 : "memory");
+}
+
+// The same three loads with one cache policy for the lanes in `tmask` (inside a leaf: triangles, read once
+// per ray and rarely shared) and another for the rest (nodes, shared by the rays of a wave and of the CU):
+// six instructions, each for part of the lanes, one wait.  RTC_TRI_LOAD_POLICY / RTC_NODE_LOAD_POLICY are the
+// policies by number, see RTC_POLICY_TEXT_n.
+#ifndef RTC_SPLIT_LOADS
+#define RTC_SPLIT_LOADS 0
+#endif
+#define RTC_POLICY_TEXT_0 ""
+#define RTC_POLICY_TEXT_1 "nt"
+#define RTC_POLICY_TEXT_2 "sc1"
+#define RTC_POLICY_TEXT_3 "sc1 nt"
+#define RTC_POLICY_TEXT_4 "sc0 sc1"
+#define RTC_POLICY_TEXT_5 "sc0"
+#define RTC_POLICY_TEXT_(id) RTC_POLICY_TEXT_##id
+#define RTC_POLICY_TEXT(id) RTC_POLICY_TEXT_(id)
+#ifndef RTC_TRI_POLICY
+#define RTC_TRI_POLICY 1
+#endif
+#ifndef RTC_NODE_POLICY
+#define RTC_NODE_POLICY 0
+#endif
+#define RTC_TRI_LOAD_POLICY RTC_POLICY_TEXT(RTC_TRI_POLICY)
+#define RTC_NODE_LOAD_POLICY RTC_POLICY_TEXT(RTC_NODE_POLICY)
+__device__ __forceinline__ void load_item_split(const float4 *p, unsigned long long tmask, float4 &a0, float4 &a1,
+                                                float4 &a2)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %3, exec\n\t"
+                 "s_and_b64 exec, %3, %5\n\t"
+                 "global_load_dwordx4 %0, %4, off " RTC_TRI_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16 " RTC_TRI_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 " RTC_TRI_LOAD_POLICY "\n\t"
+                 "s_andn2_b64 exec, %3, %5\n\t"
+                 "global_load_dwordx4 %0, %4, off " RTC_NODE_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16 " RTC_NODE_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 " RTC_NODE_LOAD_POLICY "\n\t"
+                 "s_mov_b64 exec, %3\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&s"(saved)
+                 : "v"(p), "s"(tmask)
+                 : "memory", "scc");
+}
+
+// RTC_PROBE_MISS_LOADS (measurement builds only): one more 16-byte load per lane and iteration from a
+// pseudo-random place of the item array, i.e. one more miss per lane.
+#ifndef RTC_PROBE_VALU
+#define RTC_PROBE_VALU 0
+#endif
+#ifndef RTC_PROBE_MISS_LOADS
+#define RTC_PROBE_MISS_LOADS 0
+#endif
+__device__ __forceinline__ void load_item_and_miss(const float4 *p, const float4 *far_p, float4 &a0, float4 &a1,
+                                                   float4 &a2)
+{
+    float4 x0;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(x0)
+                 : "v"(p), "v"(far_p)
                  : "memory");
 }
 
@@ -762,11 +849,25 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
 
     while (cur != kDone && (steps < max_steps || (leaf & 3u))) {
         steps++;
+#if RTC_PROBE_VALU
+        {   // measurement builds only: RTC_PROBE_VALU more vector instructions per iteration, no memory access
+            float x = r.near_t;
+#pragma unroll
+            for (int k = 0; k < RTC_PROBE_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));
+            asm volatile("" ::"v"(x));
+        }
+#endif
         if ((cur & 3u) && !(leaf & 3u)) leaf = cur; // entering a leaf
         const bool in_leaf = (leaf & 3u) != 0;
         const float4 *p = items + ((in_leaf ? leaf : cur) >> 2);
         float4 a0, a1, a2;
+#if RTC_SPLIT_LOADS
+        load_item_split(p, __ballot(in_leaf), a0, a1, a2);
+#elif RTC_PROBE_MISS_LOADS
+        load_item_and_miss(p, items + ((((cur >> 2) + steps) * 2654435761u) % 30000000u), a0, a1, a2); // scenes of 3e7 units and more only
+#else
         load_item(p, a0, a1, a2);
+#endif
         bool need_pop = false;
         if (!in_leaf) {
             need_pop = qwide_step<ANYHIT>(a0, a1, a2, slab_ray_lean(s), r.near_t, r.far_t, st, cur);
@@ -792,6 +893,104 @@ __device__ __forceinline__ void traverse_wide_steps(const SceneDev &sc, LaneStat
     s.tri = leaf;
     s.steps = steps;
 }
+// ------------------------------------------------------------------------
+// Stepwise traversal that takes a leaf and the item that follows it in one iteration (form 8).
+//
+// A wave-iteration of traverse_wide_steps() ends in a wait for the slowest gather of its lanes, and a ray
+// needs about as many iterations for its triangles, one each, as for its nodes.  After a leaf the walk
+// always goes on with the next deferred item, and
+// which one that is does not depend on the leaf's triangles.  So an iteration that stands at a leaf
+// pops that item first and loads it together with the leaf's first two triangles (nine loads in
+// flight, one wait); then the triangles are tested one after the other, and the node, against the far
+// distance they leave behind.  The visits, their order and the arithmetic are those of
+// traverse_wide_steps(): same distances, same ids.  A third triangle of a leaf (trees built with
+// leaves of three) is fetched in a pass of its own.  Measured on the San-Miguel-class bounce rays:
+// 28 % fewer wave-iterations, 6 % MORE vector instructions (the triangle code runs twice per
+// iteration, each time for fewer lanes), 93 registers (5 waves per SIMD): the launch is 3 % slower
+// than with form 2.  Kept as a measured alternative; not selected by default.
+__device__ __forceinline__ void load_leaf_and_node(const float4 *pt, unsigned long long amask, unsigned long long bmask,
+                                                   const float4 *pn, unsigned long long nmask, float4 &t0, float4 &t1,
+                                                   float2 &t2, float4 &u0, float4 &u1, float2 &u2, float4 &n0,
+                                                   float4 &n1, float4 &n2)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %9, exec\n\t"
+                 "s_mov_b64 exec, %12\n\t"
+                 "global_load_dwordx4 %0, %10, off\n\t"
+                 "global_load_dwordx4 %1, %10, off offset:16\n\t"
+                 "global_load_dwordx2 %2, %10, off offset:32\n\t"
+                 "s_mov_b64 exec, %13\n\t"
+                 "global_load_dwordx4 %3, %10, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %10, off offset:64\n\t"
+                 "global_load_dwordx2 %5, %10, off offset:80\n\t"
+                 "s_mov_b64 exec, %14\n\t"
+                 "global_load_dwordx4 %6, %11, off\n\t"
+                 "global_load_dwordx4 %7, %11, off offset:16\n\t"
+                 "global_load_dwordx4 %8, %11, off offset:32\n\t"
+                 "s_mov_b64 exec, %9\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(n0), "=&v"(n1), "=&v"(n2),
+                   "=&s"(saved)
+                 : "v"(pt), "v"(pn), "s"(amask), "s"(bmask), "s"(nmask)
+                 : "memory");
+}
+
+template <bool ANYHIT, class STACK>
+__device__ __forceinline__ void traverse_wide_pairs(const SceneDev &sc, LaneState &s, STACK &st, unsigned min_active,
+                                                    unsigned max_steps)
+{
+    static_assert(kUnitsPerItem == 3, "the second triangle of a leaf is read 48 bytes behind the first");
+    const float4 *__restrict__ items = reinterpret_cast<const float4 *>(sc.witems);
+    RayRegs &r = s.r;
+    unsigned cur = s.cur; // reference (unit << 2 | triangles) of the item the ray stands at
+    unsigned steps = s.steps;
+
+    while (cur != kDone && steps < max_steps) {
+        steps++;
+        const unsigned tris = cur & 3u;
+        const float4 *pt = items + (cur >> 2);
+        unsigned next = cur; // the item this iteration ends at: `cur` itself, or what follows the leaf
+        if (tris) next = pop_next<ANYHIT>(st, r.far_t);
+        const bool at_node = next != kDone && !(next & 3u);
+        float4 t0, t1, u0, u1, n0, n1, n2;
+        float2 t2, u2;
+        load_leaf_and_node(pt, __ballot(tris != 0), __ballot(tris >= 2), items + (next >> 2), __ballot(at_node), t0, t1,
+                           t2, u0, u1, u2, n0, n1, n2);
+        if (tris) {
+            cur = next;
+            float t = tri_test(t0, t1, t2, r.o, r.d);
+            if (t >= r.near_t && t < r.far_t) {
+                r.far_t = t;
+                s.hit = ANYHIT ? 1u : __float_as_uint(t2.y);
+            }
+            if (tris >= 2) {
+                t = tri_test(u0, u1, u2, r.o, r.d);
+                if (t >= r.near_t && t < r.far_t) {
+                    r.far_t = t;
+                    s.hit = ANYHIT ? 1u : __float_as_uint(u2.y);
+                }
+            }
+            if (kWideLeafTris > 2 && tris == 3) {
+                float4 a0, a1, a2;
+                load_item(pt + 2 * kUnitsPerItem, a0, a1, a2);
+                t = tri_test(a0, a1, make_float2(a2.x, a2.y), r.o, r.d);
+                if (t >= r.near_t && t < r.far_t) {
+                    r.far_t = t;
+                    s.hit = ANYHIT ? 1u : __float_as_uint(a2.y);
+                }
+            }
+            if (ANYHIT && s.hit == 1u) cur = kDone;
+        }
+        if (at_node && cur != kDone) {
+            if (qwide_step<ANYHIT>(n0, n1, n2, slab_ray_lean(s), r.near_t, r.far_t, st, cur))
+                cur = pop_next<ANYHIT>(st, r.far_t);
+        }
+        if ((unsigned)__popcll(__ballot(true)) < min_active) break;
+    }
+    s.cur = cur;
+    s.steps = steps;
+}
+
 // ------------------------------------------------------------------------
 // Stepwise traversal with a wave-level triangle-job queue (form 7, incoherent rays).
 //
@@ -1721,6 +1920,18 @@ struct TraceTune<true, false, 6, QueueIO> {
     static constexpr int lds_depth = RTC_TUNE_ANY6_LDS;
     static constexpr bool stack_dist = false;
 };
+template <>
+struct TraceTune<false, false, 8, QueueIO> {
+    static constexpr int waves = RTC_TUNE_EXT8_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_EXT8_LDS;
+    static constexpr bool stack_dist = false;
+};
+template <>
+struct TraceTune<true, false, 8, QueueIO> {
+    static constexpr int waves = RTC_TUNE_ANY8_WAVES;
+    static constexpr int lds_depth = RTC_TUNE_ANY8_LDS;
+    static constexpr bool stack_dist = false;
+};
 // form 7 keeps a job ring (4 KB per block) and result slots (2 KB closest-hit, 1 KB any-hit) in LDS
 // beside the stacks: 19 + 1 + 4 + 2 = 26 KB per block for six blocks per CU, 16 + 1 + 4 + 1 = 22 KB for seven
 template <class IO>
@@ -1738,13 +1949,14 @@ struct TraceTune<true, false, 7, IO> {
 #endif
 
 // The allocation-free stream entry point sizes its fixed overflow area from RTC_LDS_STACK_DEPTH entries
-// in LDS: every closest-hit kernel it can launch (forms 0..4 and 6 on StreamIO) must keep that many.
+// in LDS: every closest-hit kernel it can launch (forms 0..4, 6 and 8 on StreamIO) must keep that many.
 static_assert(TraceTune<false, false, 0, StreamIO>::lds_depth == kLdsDepth &&
                   TraceTune<false, false, 1, StreamIO>::lds_depth == kLdsDepth &&
                   TraceTune<false, false, 2, StreamIO>::lds_depth == kLdsDepth &&
                   TraceTune<false, false, 3, StreamIO>::lds_depth == kLdsDepth &&
                   TraceTune<false, false, 4, StreamIO>::lds_depth == kLdsDepth &&
-                  TraceTune<false, false, 6, StreamIO>::lds_depth == kLdsDepth,
+                  TraceTune<false, false, 6, StreamIO>::lds_depth == kLdsDepth &&
+                  TraceTune<false, false, 8, StreamIO>::lds_depth == kLdsDepth,
               "a StreamIO closest-hit kernel keeps fewer LDS stack entries than the fixed scratch assumes");
 
 template <bool ANYHIT, bool STATS, int MODE, class IO>
@@ -1752,7 +1964,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
                                                       TraceLaunch tl)
 {
     constexpr int kDepth = TraceTune<ANYHIT, STATS, MODE, IO>::lds_depth;
-    constexpr bool kWide = MODE == 2 || MODE == 3 || MODE == 6 || MODE == 7; // forms on the quantized 4-wide tree
+    constexpr bool kWide = MODE == 2 || MODE == 3 || MODE == 6 || MODE == 7 || MODE == 8; // forms on the quantized 4-wide tree
     constexpr bool kQueue = MODE == 7;                                       // triangle jobs through a wave-level ring
     constexpr bool kNonNeg = IO::kNearNonNegative;
     constexpr bool kDist = TraceTune<ANYHIT, STATS, MODE, IO>::stack_dist && kWide && !ANYHIT;
@@ -1861,6 +2073,8 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
             traverse_wide_split<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else if (MODE == 7)
             traverse_wide_queue<ANYHIT, kNonNeg>(sc, s, st, jq, ranges_left ? tl.min_active : 1u, tl.coop_steps);
+        else if (MODE == 8)
+            traverse_wide_pairs<ANYHIT>(sc, s, st, ranges_left ? tl.min_active : 1u, tl.coop_steps);
         else
             traverse_steps<ANYHIT, STATS, (MODE == 4)>(sc, s, st, cnt, ranges_left ? tl.min_active : 1u, tl.coop_steps);
 
@@ -1868,7 +2082,7 @@ __global__ __launch_bounds__(kBlock, (TraceTune<ANYHIT, STATS, MODE, IO>::waves)
         {
             // form 7: a ray is handed over once its triangle jobs are done (a leaf at hand goes with it)
             const bool inside_leaf = kQueue ? (int)(jq.head - s.tri) < 0
-                                            : (MODE == 2 || MODE == 6) ? (s.tri & 3u) != 0 : s.tri < s.tri_end;
+                                            : (MODE == 2 || MODE == 6 || MODE == 8) ? (s.tri & 3u) != 0 : s.tri < s.tri_end;
             unsigned long long parked = __ballot(s.have_ray && s.cur != kDone && s.steps >= tl.coop_steps && !inside_leaf);
             CoopItem *work = reinterpret_cast<CoopItem *>(tl.coop) + (size_t)(gtid >> 6) * tl.coop_cap;
             while (parked != 0) {
@@ -2507,7 +2721,16 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(ShadeArgs a)
         if (pred[1][it]) {
             a.rays_out[pos[1][it]] = out[it].bn_ray;
             a.infos_out[pos[1][it]] = out[it].bn_info;
-            if (a.bounce_keys) a.bounce_keys[pos[1][it]] = morton_key(a, out[it].bn_ray.o);
+            if (a.bounce_keys) {
+                unsigned key = morton_key(a, out[it].bn_ray.o);
+                if (a.key_dir_shift < 32u) {
+                    const unsigned oct = (__float_as_uint(out[it].bn_ray.d[0]) >> 31) |
+                                         ((__float_as_uint(out[it].bn_ray.d[1]) >> 31) << 1) |
+                                         ((__float_as_uint(out[it].bn_ray.d[2]) >> 31) << 2);
+                    key = (key & ~(7u << a.key_dir_shift)) | (oct << a.key_dir_shift);
+                }
+                a.bounce_keys[pos[1][it]] = key;
+            }
         }
     }
 }
@@ -2658,9 +2881,14 @@ static void launch_trace(bool anyhit, bool stats, const SceneDev &sc, const IO &
                                n_val, tl);
         return;
     }
-    if ((tl.mode == 2 || tl.mode == 3 || tl.mode == 6 || tl.mode == 7) && !stats && sc.witems) {
+    if ((tl.mode == 2 || tl.mode == 3 || tl.mode == 6 || tl.mode == 7 || tl.mode == 8) && !stats && sc.witems) {
         // 4-wide tree, no visit counters in these forms
-        if (tl.mode == 7 && tl.job_units_ok) {
+        if (tl.mode == 8) {
+            if (anyhit)
+                launch_one<true, false, 8, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+            else
+                launch_one<false, false, 8, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
+        } else if (tl.mode == 7 && tl.job_units_ok) {
             if (anyhit)
                 launch_one<true, false, 7, IO>(sc, io, n_ptr, n_val, grid, tl, stream);
             else

@@ -144,6 +144,7 @@ struct rt_ctx {
     // most triangles in a leaf of the fast forms' tree (1..3): 2 against 3 is +2 % on San-Miguel-class, +1 % on
     // dragon-class, nothing on Sponza-class; 1 gains on the deep launches and loses more on the depth-0 ones
     unsigned fast_tree_max_leaf = 2;
+    unsigned fast_tree_align = 4;         // placement of the wide tree's items against 128-byte lines, see layout_wide4()
     unsigned trav_mode[2] = {3, 2};
     unsigned trav_deep_connect = 0xFFFFFFFFu; // form of the deeper any-hit launches; 0xFFFFFFFF: trav_mode[1]
     // the stream entry points are the reference's Bvh::intersect_stream / occluded_stream
@@ -156,6 +157,7 @@ struct rt_ctx {
     // on (depth of the launch that consumes the queue); 0xFFFFFFFF = never
     unsigned sort_from_depth[2] = {0xFFFFFFFFu, 1}; // [0] extend (never), [1] connect
     unsigned sort_bits = 21;              // high bits of the 30-bit key that are sorted
+    unsigned sort_octant = 0;             // bounce rays: the direction's octant in the three lowest sorted bits
     Workspace ws;
     // Queue lengths of the last finished render pass, read back asynchronously: the next pass
     // sorts only that many entries (+ slack) of each queue instead of the whole allocation.
@@ -330,7 +332,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_FUSE_PRIMARY")) ctx->fuse_primary = atoi(env) ? 1u : 0u;
     if (const char *env = getenv("RTCORE_TRAVERSAL_STREAM")) {
         int v = atoi(env);
-        if (v >= 0 && v <= 7) ctx->trav_stream = (unsigned)v;
+        if (v >= 0 && v <= 8) ctx->trav_stream = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEPTH0")) {
         int v = atoi(env);
@@ -338,11 +340,11 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP")) {
         int v = atoi(env);
-        if ((v >= 0 && v <= 3) || (v >= 5 && v <= 7)) ctx->trav_mode[1] = (unsigned)v;
+        if ((v >= 0 && v <= 3) || (v >= 5 && v <= 8)) ctx->trav_mode[1] = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_TRAVERSAL_DEEP_CONNECT")) {
         int v = atoi(env);
-        if ((v >= 0 && v <= 3) || (v >= 5 && v <= 7)) ctx->trav_deep_connect = (unsigned)v;
+        if ((v >= 0 && v <= 3) || (v >= 5 && v <= 8)) ctx->trav_deep_connect = (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_SORT_EXTEND_FROM")) ctx->sort_from_depth[0] = (unsigned)atoi(env);
     if (const char *env = getenv("RTCORE_SORT_CONNECT_FROM")) ctx->sort_from_depth[1] = (unsigned)atoi(env);
@@ -350,6 +352,7 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
         int v = atoi(env);
         if (v >= 3 && v <= 30) ctx->sort_bits = (unsigned)v;
     }
+    if (const char *env = getenv("RTCORE_SORT_OCTANT")) ctx->sort_octant = atoi(env) != 0;
     if (const char *env = getenv("RTCORE_COOP_STEPS")) {
         long long v = atoll(env);
         ctx->coop_steps = (v <= 0 || v >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)v;
@@ -461,13 +464,15 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->fast_tree_device_build = (unsigned)value;
     } else if (n == "fast_tree_max_leaf" && in(1, kWideLeafTris)) {
         ctx->fast_tree_max_leaf = (unsigned)value;
-    } else if (n == "traversal_stream" && in(0, 7)) {
+    } else if (n == "fast_tree_align" && (in(0, 1) || in(3, 4))) {
+        ctx->fast_tree_align = (unsigned)value;
+    } else if (n == "traversal_stream" && in(0, 8)) {
         ctx->trav_stream = (unsigned)value;
     } else if (n == "traversal_depth0" && in(0, 3)) {
         ctx->trav_mode[0] = (unsigned)value;
-    } else if (n == "traversal_deep" && (in(0, 3) || in(5, 7))) {
+    } else if (n == "traversal_deep" && (in(0, 3) || in(5, 8))) {
         ctx->trav_mode[1] = (unsigned)value;
-    } else if (n == "traversal_deep_connect" && (value == -1 || in(0, 3) || in(5, 7))) {
+    } else if (n == "traversal_deep_connect" && (value == -1 || in(0, 3) || in(5, 8))) {
         ctx->trav_deep_connect = value < 0 ? 0xFFFFFFFFu : (unsigned)value;
     } else if (n == "sort_extend_from" && in(0, 0xFFFFFFFFll)) {
         ctx->sort_from_depth[0] = (unsigned)value;
@@ -475,6 +480,8 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->sort_from_depth[1] = (unsigned)value;
     } else if (n == "sort_bits" && in(3, 30)) {
         ctx->sort_bits = (unsigned)value;
+    } else if (n == "sort_octant" && in(0, 1)) {
+        ctx->sort_octant = (unsigned)value;
     } else if (n == "timing" && in(0, 1)) {
         ctx->timing = value != 0;
     } else {
@@ -876,8 +883,11 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     WideLayout layout;
     uint32_t wide_depth = 0, extra_depth = 0, fast_depth = 0;
     int fast_error = 0; // 1: a leaf too large for the wide tree, 2: too many units (reported on the calling thread)
-    unsigned align_mode = 0;
-    if (const char *env = getenv("RTCORE_WIDE_ALIGN")) align_mode = (unsigned)atoi(env);
+    unsigned align_mode = ctx->fast_tree_align;
+    if (const char *env = getenv("RTCORE_WIDE_ALIGN")) {
+        const int v = atoi(env);
+        if (v == 0 || v == 1 || v == 3 || v == 4) align_mode = (unsigned)v;
+    }
     // from a binary tree (search tree, or the reference's with fast_tree_buckets = 0) to the packed items
     auto fast_pipeline = [&](const rt_flat_node *nodes, size_t num_nodes, uint32_t root_ref, uint32_t root_count,
                              const std::vector<uint32_t> &order, uint32_t depth, uint32_t max_objs) {
@@ -904,7 +914,9 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         const uint32_t wroot = collapse_wide4(xdn.data(), xdn.size(), xroot, wn, &wide_depth);
         phase("  4-wide collapse");
         sc->num_wide_nodes = (uint32_t)wn.size();
-        if (!layout_wide4(wn, wroot, num_triangles, layout, align_mode)) {
+        // a children block spread beyond its six address bits by alignment gaps: the packed placement always fits
+        if (!layout_wide4(wn, wroot, num_triangles, layout, align_mode) &&
+            (align_mode == 0 || !layout_wide4(wn, wroot, num_triangles, layout, 0))) {
             fast_error = 1;
             return;
         }
@@ -1390,7 +1402,7 @@ extern "C" int rt_intersect_stream_noalloc(rt_scene *sc, rt_stream_ray *d_rays, 
         // deferred nodes a ray of the selected form can hold: one sibling per level of the binary tree, up to
         // three children per level of the wide one
         const unsigned form = ctx->trav_stream;
-        const bool wide = (form == 2 || form == 3 || form == 5 || form == 6 || form == 7) && sc->dev.witems;
+        const bool wide = (form == 2 || form == 3 || form >= 5) && sc->dev.witems;
         const unsigned bound = wide ? 3u * sc->dev.wmax_depth + 1u : sc->dev.max_depth + 1u;
         if (bound > RT_NOALLOC_MAX_STACK)
             return fail(RT_ERR_LIMIT,
@@ -1890,6 +1902,7 @@ extern "C" int rt_render_device(rt_scene *sc, const rt_camera *camera, const rt_
                     a.key_scale[k] = sc->key_scale[k];
                 }
                 a.key_mask = (0x3FFFFFFFu >> (30u - ctx->sort_bits)) << (30u - ctx->sort_bits);
+                a.key_dir_shift = ctx->sort_octant ? 30u - ctx->sort_bits : 32u;
                 a.shadow_keys = sort_shadow ? (uint32_t *)w.keys[1].p : nullptr;
                 a.bounce_keys = sort_bounce ? (uint32_t *)w.keys[0].p : nullptr;
                 rc = timed_begin(ctx, 2, s, &slot);

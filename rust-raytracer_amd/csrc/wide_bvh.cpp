@@ -442,9 +442,23 @@ uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const 
 bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
                   unsigned align_mode)
 {
-    // align_mode 0: items back to back; 1: nodes start on 64-byte lines; 2: every item does
+    // align_mode 0: items back to back; 1: nodes start on 64-byte lines; 2: every item does; 3: no item lies
+    // across a 128-byte line (8 units), gaps only where one would; 4: as 3, and a leaf of one or two triangles
+    // lies within one line
+    auto crosses = [](uint32_t unit) { return (unit & 7u) > 8u - kUnitsPerItem; };
     auto place = [&](uint32_t &next, bool node) {
         if (align_mode == 2 || (align_mode == 1 && node)) next = (next + 3u) & ~3u;
+        if (align_mode >= 3 && node)
+            while (crosses(next)) next++;
+    };
+    auto place_leaf = [&](uint32_t &next, uint32_t count) {
+        if (align_mode < 3) return;
+        for (;; next++) {
+            bool ok = true;
+            for (uint32_t t = 0; t < count; t++) ok = ok && !crosses(next + kUnitsPerItem * t);
+            if (align_mode == 4 && kUnitsPerItem * count <= 8u) ok = ok && (next & 7u) + kUnitsPerItem * count <= 8u;
+            if (ok) return;
+        }
     };
     out.node_unit.assign(wide.size(), 0xFFFFFFFFu);
     out.slot_unit.assign(num_triangles, 0xFFFFFFFFu);
@@ -476,6 +490,11 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
         while (used < 4 && std::isfinite(n.lo[0][used])) used++;
         uint32_t inner[4];
         int ninner = 0;
+        uint32_t block_first = 0xFFFFFFFFu; // a child is addressed by six bits of units past the block's first item
+        auto in_block = [&](uint32_t unit) {
+            if (block_first == 0xFFFFFFFFu) block_first = unit;
+            return unit - block_first < 64u;
+        };
         for (int i = 0; i < used; i++) {
             const uint32_t ref = n.child[i];
             if (ref & kLeafBit) {
@@ -484,11 +503,14 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
                 if (align_mode == 2) {
                     return false; // leaves must stay contiguous: not supported with per-item alignment
                 }
+                place_leaf(next, count);
+                if (!in_block(next)) return false;
                 for (uint32_t t = 0; t < count; t++) out.slot_unit[first + t] = next + kUnitsPerItem * t;
                 next += kUnitsPerItem * count;
             } else {
                 if (ref >= wide.size() || out.node_unit[ref] != 0xFFFFFFFFu) return false;
                 place(next, true);
+                if (!in_block(next)) return false;
                 out.node_unit[ref] = next;
                 next += kUnitsPerItem;
                 inner[ninner++] = ref;

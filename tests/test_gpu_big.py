@@ -97,7 +97,7 @@ def test_big_trace_fast_forms(O, rt, ctx_default, big):
     tree, stepwise and while-while) on the same rays: the oracle's distances except for a ray the
     binary walk culls at a box face, which must then agree with brute force."""
     prim, rnd, bounce, shadow = make_ray_sets(O, big)
-    for form in (2, 3, 5, 6, 7):
+    for form in (2, 3, 5, 6, 7, 8):
         ctx_default.set_option("traversal_stream", form)
         for rays, what in ((prim, "primary"), (bounce, "bounce-like"), (shadow, "finite far")):
             io, to, _ = big.So.intersect_stream(rays)
@@ -269,7 +269,7 @@ def test_deep_stack_fast_forms(O, rt, ctx_default, coop):
     io, to, _ = So.intersect_stream(rays)
     oo, _ = So.occluded1(rays)
     ctx.set_option("coop_steps", coop)
-    for form in (2, 3, 5, 6, 7):
+    for form in (2, 3, 5, 6, 7, 8):
         ctx.set_option("traversal_stream", form)
         ig, tg, _ = Sg.intersect_stream(rays, stats=False)
         assert np.array_equal(tg, to), form

@@ -53,7 +53,7 @@ def check_closest(O, sc, So, rays, io, to, ig, tg, rt, n_ordinary):
     return int(diff.size)
 
 
-@pytest.mark.parametrize("form", [2, 3, 5, 6, 7])
+@pytest.mark.parametrize("form", [2, 3, 5, 6, 7, 8])
 @pytest.mark.parametrize("coop", [0, 5, 4096])
 def test_wide_trace_parity(O, rt, ctx_default, scenes, coop, form):
     ctx = ctx_default
@@ -113,7 +113,7 @@ def test_wide_stats_request_runs_binary_form(O, rt, ctx, scenes):
 
 @pytest.mark.parametrize("name,kw,W,H,spp,b", [("cornell-class", {}, 96, 54, 4, 2),
                                                ("test-mesh", {"n_tris": 4000, "seed": 9}, 80, 45, 4, 3)])
-@pytest.mark.parametrize("forms", [(3, 2), (2, 3), (3, 5), (3, 6), (3, 7)])
+@pytest.mark.parametrize("forms", [(3, 2), (2, 3), (3, 5), (3, 6), (3, 7), (3, 8)])
 def test_wide_render_parity(O, rt, ctx_default, scenes, name, kw, W, H, spp, b, forms):
     ctx = ctx_default
     sc = scenes.load(name, **kw)
@@ -157,7 +157,7 @@ def test_full_size_fast_mode_against_exact_mode(rt, ctx, ctx_default, scenes, na
     assert rmse < 2e-3, rmse
 
 
-@pytest.mark.parametrize("form", [2, 3, 5, 6, 7])
+@pytest.mark.parametrize("form", [2, 3, 5, 6, 7, 8])
 def test_fast_forms_on_degenerate_leaves(O, rt, ctx_default, scenes, form):
     """A mesh whose tree has a root leaf, and one with clusters of 20 coincident triangles inside a
     larger mesh (leaves beyond 8 triangles in both builders): the fast forms still find the oracle's hits."""
@@ -199,3 +199,37 @@ def test_fast_forms_on_degenerate_leaves(O, rt, ctx_default, scenes, form):
         Sg.close()
     finally:
         ctx.set_option("traversal_stream", 1)
+
+
+@pytest.mark.parametrize("max_leaf", [1, 2, 3])
+@pytest.mark.parametrize("coop", [0, 4096])   # a hand-over to the cooperative finish after 5 iterations comes at
+                                              # another item in the two forms, and that walk has its own tie order
+def test_form8_is_form2_bit_for_bit(O, rt, ctx_default, scenes, coop, max_leaf):
+    """Form 8 takes a leaf and the item that follows it in one iteration; the visits, their order and the
+    arithmetic are those of form 2, so ids (ties included), distances and occlusion flags are equal bit for
+    bit -- on trees with leaves of one, two and three triangles (the third is fetched in a pass of its own)."""
+    ctx = ctx_default
+    ctx.set_option("coop_steps", coop)
+    ctx.set_option("fast_tree_max_leaf", max_leaf)
+    try:
+        for name, kw in SCENES:
+            sc = scenes.load(name, **kw)
+            Sg = rt.Scene(ctx, sc.positions, sc.indices, sc.geom_normals)
+            lo, hi = float(sc.positions.min()), float(sc.positions.max())
+            rays = np.concatenate([O.generate_primary(sc.camera, 96, 54, 1),
+                                   random_rays(O.make_rays, 30000, 5, lo=lo, hi=hi),
+                                   adversarial_rays(O.make_rays, sc.positions)])
+            out = {}
+            for form in (2, 8):
+                ctx.set_option("traversal_stream", form)
+                ids, t, _ = Sg.intersect_stream(rays.copy(), stats=False)
+                occ, _ = Sg.occluded_stream(rays.copy(), stats=False)
+                out[form] = (ids, t, occ)
+            assert np.array_equal(out[2][0], out[8][0]), name
+            assert np.array_equal(out[2][1].view(np.uint32), out[8][1].view(np.uint32)), name
+            assert np.array_equal(out[2][2], out[8][2]), name
+            Sg.close()
+    finally:
+        ctx.set_option("traversal_stream", 1)
+        ctx.set_option("coop_steps", 4096)
+        ctx.set_option("fast_tree_max_leaf", 2)
