@@ -365,7 +365,8 @@ def make_roofline(rec, pmc, pmc_file):
     rocprofv3 --pmc passes (None when there is no profile of this build).
 
     `bound` names the most-utilised unit the counters show and `frac` is that unit's busy fraction:
-    the vector-memory address unit (TA_TA_BUSY / (256 CUs x kernel cycles)), VALU issue
+    the vector-memory address unit (TA_TA_BUSY / (256 CUs x kernel cycles)), the L1 tag pipeline behind it
+    (TCP_TOTAL_CACHE_ACCESSES / (256 CUs x kernel cycles): one line access per clock), VALU issue
     (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles)) or HBM (measured bytes / time / peak).
     The HBM side is kept under `hbm`: bytes from FETCH_SIZE x the calibrated factor + WRITE_SIZE, the
     part of them the kernel asked for (L2 misses x 48-byte items), and the reminder that FETCH_SIZE
@@ -422,6 +423,11 @@ def make_roofline(rec, pmc, pmc_file):
         u["address_unit_stalled_by_cache_frac"] = round(pmc["address_unit_stalled_by_cache"], 4)
     if h["frac"] is not None:
         u["hbm_frac"] = h["frac"]
+    if "l1_accesses_per_clock_per_cu" in pmc:
+        # one access = one line touched by one vector memory instruction; the L1 takes one per clock
+        u["l1_pipeline_frac"] = round(min(1.0, pmc["l1_accesses_per_clock_per_cu"]), 4)
+    if "l1_fill_latency_cycles" in pmc:
+        u["l1_fill_latency_cycles"] = round(pmc["l1_fill_latency_cycles"], 1)
     for k in ("l1_hit_rate", "l2_hit_rate", "kernel_cycles", "valu_instructions_per_launch",
               "vector_loads_per_launch"):
         if k in pmc:
@@ -435,6 +441,9 @@ def make_roofline(rec, pmc, pmc_file):
     if "valu_issue_frac" in u:
         cands.append((u["valu_issue_frac"], "VALU issue (2 cycles per wave64 instruction)", u["valu_issue_frac"] * cyc, cyc,
                       "cycles per SIMD per launch"))
+    if "l1_pipeline_frac" in u:
+        cands.append((u["l1_pipeline_frac"], "L1 tag pipeline (one line access per clock and CU)",
+                      u["l1_pipeline_frac"] * cyc, cyc, "accesses per CU per launch"))
     if h["frac"] is not None:
         cands.append((h["frac"], "hbm", h["achieved"], HBM_PEAK_GBS, "GB/s"))
     if cands:

@@ -28,7 +28,7 @@ for wl in ${STATS_WORKLOADS-san-miguel-class sponza-class dragon-class}; do
 done
 [ -n "$SKIP_PMC" ] && WORKLOADS=" "
 for wl in ${WORKLOADS-san-miguel-class sponza-class}; do
-  WORKLOAD=$wl TAG=$TAG PASSES="${PASSES:-1 2 3 4 5 6 8}" bash scripts/gpu_pmc.sh > $OUT/pmc_$wl.log 2>&1 || { tail -30 $OUT/pmc_$wl.log; exit 1; }
+  WORKLOAD=$wl TAG=$TAG PASSES="${PASSES:-1 2 3 4 5 6 8 11}" bash scripts/gpu_pmc.sh > $OUT/pmc_$wl.log 2>&1 || { tail -30 $OUT/pmc_$wl.log; exit 1; }
   python3 scripts/pmc_to_json.py gpurun_out/pmc_${wl}_$TAG $wl > $OUT/pmc_$wl.json
   cp gpurun_out/pmc_${wl}_$TAG/summary.txt $OUT/pmc_${wl}_summary.txt
 done

@@ -79,6 +79,14 @@ def record(c):
         rec["vector_loads_per_launch"] = m["SQ_INSTS_VMEM_RD"]
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in m and "TCP_TCC_READ_REQ_sum" in m:
         rec["l1_hit_rate"] = 1.0 - m["TCP_TCC_READ_REQ_sum"] / max(1.0, m["TCP_TOTAL_CACHE_ACCESSES_sum"])
+    if cyc > 0 and "TCP_TOTAL_CACHE_ACCESSES_sum" in m:
+        # one access = one line touched by one vector memory instruction; the L1 takes one per clock
+        rec["l1_accesses_per_clock_per_cu"] = m["TCP_TOTAL_CACHE_ACCESSES_sum"] / CUS / cyc
+        rec["l1_accesses_per_launch"] = m["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    if "TCP_TCC_READ_REQ_sum" in m:
+        rec["l1_fills_per_launch"] = m["TCP_TCC_READ_REQ_sum"]
+        if m.get("TCP_TCC_READ_REQ_LATENCY_sum"):
+            rec["l1_fill_latency_cycles"] = m["TCP_TCC_READ_REQ_LATENCY_sum"] / max(1.0, m["TCP_TCC_READ_REQ_sum"])
     for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
         if k in m:
             rec[k] = m[k]
