@@ -16,7 +16,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <stdexcept>
 #include <thread>
@@ -72,21 +78,150 @@ inline uint32_t bucket_of(float k0, float k1, float c)
     return (uint32_t)f;
 }
 
+// Worker threads that stay alive for the top phase of one build: a node of the top levels makes up to six
+// parallel passes over its range, and a thread started for each slice of each pass costs more than the pass.
+class SlicePool {
+  public:
+    explicit SlicePool(unsigned workers)
+    {
+        for (unsigned t = 0; t < workers; t++) threads_.emplace_back([this, t] { loop(t + 1); });
+    }
+    ~SlicePool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            generation_++;
+        }
+        start_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    unsigned workers() const { return (unsigned)threads_.size(); }
+    // job(t) for t = 1..workers on the pool's threads and job(0) on the caller's; returns when all are done
+    void run(const std::function<void(unsigned)> &job)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &job;
+            pending_ = (unsigned)threads_.size();
+            generation_++;
+        }
+        start_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop(unsigned t)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                start_.wait(g, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                job = job_;
+            }
+            (*job)(t);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable start_, done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned pending_ = 0;
+    unsigned long generation_ = 0;
+    bool stop_ = false;
+};
+// the pool of the build running on this thread, if it has one (builds of two trees run side by side)
+thread_local SlicePool *t_pool = nullptr;
+
 // Runs fn(t, lo, hi) on `threads` threads over [begin, end) cut into equal slices.
 template <class F>
 void parallel_slices(unsigned threads, uint32_t begin, uint32_t end, F fn)
 {
     const uint32_t n = end - begin;
+    auto slice = [&](unsigned t) {
+        fn(t, begin + (uint32_t)((uint64_t)n * t / threads), begin + (uint32_t)((uint64_t)n * (t + 1) / threads));
+    };
+    if (t_pool && t_pool->workers() + 1 == threads) {
+        t_pool->run(slice);
+        return;
+    }
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; t++)
-        pool.emplace_back([=, &fn] { fn(t, begin + (uint32_t)((uint64_t)n * t / threads), begin + (uint32_t)((uint64_t)n * (t + 1) / threads)); });
-    fn(0u, begin, begin + (uint32_t)((uint64_t)n / threads));
+    for (unsigned t = 1; t < threads; t++) pool.emplace_back([&slice, t] { slice(t); });
+    slice(0u);
     for (auto &th : pool) th.join();
 }
 
 // ranges of at least this many triangles are scanned by all threads of the top phase (the unions and
 // counts are exact whatever the order, so the tree does not depend on it)
-constexpr uint32_t kParallelScan = 1u << 17;
+constexpr uint32_t kParallelScan = 1u << 15;
+
+// The reference's in-place partition (src/bvh/build.rs:152-168: scan up to the first element that belongs
+// right, scan down to the first that belongs left, swap, repeat) on several threads, with the same result
+// element for element.  That loop ends with the m elements that belong left in front, and what it swaps is
+// fixed by the input alone: the i-th misplaced element of [0, m) counted from the front with the i-th
+// misplaced element of [m, n) counted from the back; everything else stays where it is.  So: flag every
+// element (one gather of its centroid each), count, list the misplaced positions of both sides by slice
+// with prefix offsets, swap the pairs.  Returns m.
+template <class Pred>
+uint32_t parallel_hoare_partition(unsigned threads, uint32_t *idx, uint32_t n, Pred goes_left)
+{
+    std::vector<unsigned char> flag(n);
+    std::vector<uint32_t> count(threads + 1, 0);
+    parallel_slices(threads, 0, n, [&](unsigned t, uint32_t lo, uint32_t hi) {
+        uint32_t c = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            const unsigned char f = goes_left(idx[i]) ? 1 : 0;
+            flag[i] = f;
+            c += f;
+        }
+        count[t + 1] = c;
+    });
+    for (unsigned t = 0; t < threads; t++) count[t + 1] += count[t];
+    const uint32_t m = count[threads];
+    if (m == 0 || m == n) return m;
+    // misplaced positions: in [0, m) the elements that belong right, in [m, n) those that belong left
+    std::vector<uint32_t> wrong_front(threads + 1, 0), wrong_back(threads + 1, 0);
+    parallel_slices(threads, 0, n, [&](unsigned t, uint32_t lo, uint32_t hi) {
+        uint32_t a = 0, b = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            a += (i < m && !flag[i]);
+            b += (i >= m && flag[i]);
+        }
+        wrong_front[t + 1] = a;
+        wrong_back[t + 1] = b;
+    });
+    for (unsigned t = 0; t < threads; t++) {
+        wrong_front[t + 1] += wrong_front[t];
+        wrong_back[t + 1] += wrong_back[t];
+    }
+    const uint32_t k = wrong_front[threads]; // == wrong_back[threads]
+    std::vector<uint32_t> front(k), back(k);
+    parallel_slices(threads, 0, n, [&](unsigned t, uint32_t lo, uint32_t hi) {
+        uint32_t a = wrong_front[t], b = wrong_back[t];
+        for (uint32_t i = lo; i < hi; i++) {
+            if (i < m) {
+                if (!flag[i]) front[a++] = i;
+            } else if (flag[i]) {
+                back[b++] = i;
+            }
+        }
+    });
+    parallel_slices(threads, 0, k, [&](unsigned, uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; i++) std::swap(idx[front[i]], idx[back[k - 1 - i]]);
+    });
+    return m;
+}
 
 struct Work {
     uint32_t begin, end; // range in the order array
@@ -299,11 +434,17 @@ void build_range(const Prim *prims, uint32_t *order, uint32_t begin, uint32_t en
         // The reference's loops (src/bvh/build.rs:152-168) stop on a checked index; here the bounds
         // are explicit, and a partition with an empty side (impossible for finite centroids: the
         // smallest one is in bucket 0, the largest in the last) ends the subtree with a leaf.
-        for (;;) {
-            while (left < n && bucket_of(k0, k1, prims[idx[left]].c[axis]) <= min_bucket) left++;
-            while (right > 0 && bucket_of(k0, k1, prims[idx[right]].c[axis]) > min_bucket) right--;
-            if (left >= right) break;
-            std::swap(idx[left], idx[right]);
+        if (scan_threads > 1 && n >= kParallelScan) {
+            left = parallel_hoare_partition(scan_threads, idx, n, [&](uint32_t prim) {
+                return bucket_of(k0, k1, prims[prim].c[axis]) <= min_bucket;
+            });
+        } else {
+            for (;;) {
+                while (left < n && bucket_of(k0, k1, prims[idx[left]].c[axis]) <= min_bucket) left++;
+                while (right > 0 && bucket_of(k0, k1, prims[idx[right]].c[axis]) > min_bucket) right--;
+                if (left >= right) break;
+                std::swap(idx[left], idx[right]);
+            }
         }
         uint32_t split = left;
         if (split == 0 || split >= n) {
@@ -382,6 +523,15 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
         }
     };
     if (threads < 1) threads = 1;
+    const bool verbose = getenv("RTCORE_VERBOSE") != nullptr && nt >= 200000;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  host build (%s): %-22s %.3f s\n", search ? "search" : "reference", what,
+                std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     if (threads == 1 || nt < 200000) {
         fill(0, nt);
         Emit e;
@@ -404,12 +554,24 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
         for (auto &t : pool) t.join();
     }
 
+    mark("centroids and boxes");
     // top phase: expand until ranges are small, remember the rest as tasks
     Emit top;
     std::vector<Deferred> tasks;
     uint32_t grain = std::max<uint32_t>(4096, nt / (threads * 8));
-    run_range(search, prims.data(), out.order.data(), 0, nt, 0, top, &tasks, grain, true, tune, threads);
+    {
+        SlicePool pool(threads - 1);
+        t_pool = &pool;
+        try {
+            run_range(search, prims.data(), out.order.data(), 0, nt, 0, top, &tasks, grain, true, tune, threads);
+        } catch (...) {
+            t_pool = nullptr;
+            throw;
+        }
+        t_pool = nullptr;
+    }
 
+    mark("top levels");
     // parallel phase: every task builds its subtree with local node indices
     std::vector<Emit> sub(tasks.size());
     std::atomic<size_t> next{0};
@@ -427,6 +589,7 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
         for (auto &t : pool) t.join();
     }
 
+    mark("subtrees");
     bool failed = top.failed;
     for (const Emit &se : sub) failed = failed || se.failed;
     if (failed) throw std::invalid_argument(kDegenerate);
@@ -462,20 +625,32 @@ void build_bvh(const float *positions, uint32_t nv, const uint32_t *indices, uin
         nd.right = map_top_ref(nd.right, nd.right_count);
         out.nodes[top_final[i]] = nd;
     }
-    for (size_t t = 0; t < tasks.size(); t++) {
-        uint32_t base = task_base[t];
-        for (size_t i = 0; i < sub[t].nodes.size(); i++) {
-            rt_flat_node nd = sub[t].nodes[i];
-            if (!(nd.left & kLeaf)) nd.left += base;
-            if (!(nd.right & kLeaf)) nd.right += base;
-            out.nodes[base + i] = nd;
-        }
-        merge_stats(top.stats, sub[t].stats);
+    {
+        std::atomic<size_t> next_task{0};
+        auto copy_tasks = [&]() {
+            for (;;) {
+                const size_t t = next_task.fetch_add(1);
+                if (t >= tasks.size()) break;
+                const uint32_t base = task_base[t];
+                for (size_t i = 0; i < sub[t].nodes.size(); i++) {
+                    rt_flat_node nd = sub[t].nodes[i];
+                    if (!(nd.left & kLeaf)) nd.left += base;
+                    if (!(nd.right & kLeaf)) nd.right += base;
+                    out.nodes[base + i] = nd;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < threads; i++) pool.emplace_back(copy_tasks);
+        copy_tasks();
+        for (auto &t : pool) t.join();
     }
+    for (size_t t = 0; t < tasks.size(); t++) merge_stats(top.stats, sub[t].stats);
     out.stats = top.stats;
     uint32_t rc = top.root_count;
     out.root_ref = map_top_ref(top.root_ref, rc);
     out.root_count = rc;
+    mark("splice");
 }
 
 } // namespace rtc
