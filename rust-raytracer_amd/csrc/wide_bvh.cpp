@@ -1,4 +1,5 @@
 #include "wide_bvh.hpp"
+#include "wide_node_ops.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -12,29 +13,25 @@ namespace rtc {
 
 namespace {
 
-struct Slot {
-    uint32_t ref;
-    float lo[3], hi[3];
-    float area() const
-    {
-        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
-        return 2.f * (x * y + x * z + y * z);
-    }
-};
+using Slot = WideSlot;
 
 // child boxes of a binary node: lanes {minL, minR, maxL, maxR}
-void children_of(const DevNode &n, Slot &l, Slot &r)
-{
-    const float *b[3] = {n.bx, n.by, n.bz};
-    for (int k = 0; k < 3; k++) {
-        l.lo[k] = b[k][0];
-        r.lo[k] = b[k][1];
-        l.hi[k] = b[k][2];
-        r.hi[k] = b[k][3];
+struct DevNodeTree {
+    const DevNode *bn;
+    void children(uint32_t bin, Slot &l, Slot &r) const
+    {
+        const DevNode &n = bn[bin];
+        const float *b[3] = {n.bx, n.by, n.bz};
+        for (int k = 0; k < 3; k++) {
+            l.lo[k] = b[k][0];
+            r.lo[k] = b[k][1];
+            l.hi[k] = b[k][2];
+            r.hi[k] = b[k][3];
+        }
+        l.ref = n.left;
+        r.ref = n.right;
     }
-    l.ref = n.left;
-    r.ref = n.right;
-}
+};
 
 struct Pending {
     uint32_t bin;    // binary node to collapse
@@ -70,46 +67,11 @@ void run_parallel(unsigned n, F fn)
     fn(0);
 }
 
-// The wide node over binary node `bin`: children of inner children are pulled up, largest surface
-// area first, until there are four; returns how many slots are used.
+// The wide node over binary node `bin` (collapse_slots() in wide_node_ops.hpp); returns how many slots are used.
 int collapse_node(const DevNode *bn, uint32_t bin, DevWideNode &w, Slot (&c)[4])
 {
-    const float inf = std::numeric_limits<float>::infinity();
-    int n = 2;
-    children_of(bn[bin], c[0], c[1]);
-    while (n < 4) {
-        int pick = -1;
-        float best = -1.f;
-        for (int i = 0; i < n; i++) {
-            if (c[i].ref & kLeafBit) continue;
-            const float a = c[i].area();
-            if (pick < 0 || a > best) {
-                pick = i;
-                best = a;
-            }
-        }
-        if (pick < 0) break;
-        // the two children take the place of the opened child
-        for (int i = n - 1; i > pick; i--) c[i + 1] = c[i];
-        const uint32_t opened = c[pick].ref;
-        children_of(bn[opened], c[pick], c[pick + 1]);
-        n++;
-    }
-    // Slot order is the order the any-hit walk visits hit children in.  Left to right (the
-    // binary tree's order, which follows the split axis whatever the ray's direction) measured
-    // 3-20 % slower there than any order by box size; largest first is the one kept.  The
-    // closest-hit walk orders by entry distance and only falls back to slots on ties.
-    std::stable_sort(c, c + n, [](const Slot &a, const Slot &b) { return a.area() > b.area(); });
-    for (int i = 0; i < 4; i++) {
-        const bool used = i < n;
-        for (int k = 0; k < 3; k++) {
-            w.lo[k][i] = used ? c[i].lo[k] : inf;
-            w.hi[k][i] = used ? c[i].hi[k] : -inf;
-        }
-        w.child[i] = used ? c[i].ref : c[0].ref; // n < 4 only when every child is a leaf
-    }
-    w.bin = bin;
-    w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    const int n = collapse_slots(DevNodeTree{bn}, bin, c);
+    fill_wide_node(c, n, bin, w);
     return n;
 }
 
@@ -439,8 +401,11 @@ uint32_t refine_leaves(const std::vector<DevNode> &bn, uint32_t root_ref, const 
     return deep;
 }
 
-bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
-                  unsigned align_mode)
+namespace {
+// children(w, refs) gives the used child references of wide node w and returns how many there are
+template <class Children>
+bool layout_wide4_of(size_t num_wide, Children children, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
+                     unsigned align_mode)
 {
     // align_mode 0: items back to back; 1: nodes start on 64-byte lines; 2: every item does; 3: no item lies
     // across a 128-byte line (8 units), gaps only where one would; 4: as 3, and a leaf of one or two triangles
@@ -460,7 +425,7 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
             if (ok) return;
         }
     };
-    out.node_unit.assign(wide.size(), 0xFFFFFFFFu);
+    out.node_unit.assign(num_wide, 0xFFFFFFFFu);
     out.slot_unit.assign(num_triangles, 0xFFFFFFFFu);
     out.num_units = 0;
     auto leaf_range = [](uint32_t ref, uint32_t &first, uint32_t &count) {
@@ -477,7 +442,7 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
         out.root_ref = count;
         return true;
     }
-    if (wroot >= wide.size()) return false;
+    if (wroot >= num_wide) return false;
     out.node_unit[wroot] = 0;
     next = kUnitsPerItem;
     out.root_ref = 0;
@@ -485,9 +450,8 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
     while (!todo.empty()) {
         const uint32_t w = todo.back();
         todo.pop_back();
-        const DevWideNode &n = wide[w];
-        int used = 0;
-        while (used < 4 && std::isfinite(n.lo[0][used])) used++;
+        uint32_t refs[4];
+        const int used = children(w, refs);
         uint32_t inner[4];
         int ninner = 0;
         uint32_t block_first = 0xFFFFFFFFu; // a child is addressed by six bits of units past the block's first item
@@ -496,7 +460,7 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
             return unit - block_first < 64u;
         };
         for (int i = 0; i < used; i++) {
-            const uint32_t ref = n.child[i];
+            const uint32_t ref = refs[i];
             if (ref & kLeafBit) {
                 uint32_t first, count;
                 if (!leaf_range(ref, first, count) || first + count > num_triangles) return false;
@@ -508,7 +472,7 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
                 for (uint32_t t = 0; t < count; t++) out.slot_unit[first + t] = next + kUnitsPerItem * t;
                 next += kUnitsPerItem * count;
             } else {
-                if (ref >= wide.size() || out.node_unit[ref] != 0xFFFFFFFFu) return false;
+                if (ref >= num_wide || out.node_unit[ref] != 0xFFFFFFFFu) return false;
                 place(next, true);
                 if (!in_block(next)) return false;
                 out.node_unit[ref] = next;
@@ -521,76 +485,50 @@ bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t
     out.num_units = next;
     return true;
 }
+} // namespace
+
+bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
+                  unsigned align_mode)
+{
+    return layout_wide4_of(
+        wide.size(),
+        [&](uint32_t w, uint32_t (&refs)[4]) {
+            const int used = wide_children_used(wide[w]);
+            for (int i = 0; i < used; i++) refs[i] = wide[w].child[i];
+            return used;
+        },
+        wroot, num_triangles, out, align_mode);
+}
+
+bool layout_wide4(const uint32_t *children, size_t num_wide, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
+                  unsigned align_mode)
+{
+    return layout_wide4_of(
+        num_wide,
+        [&](uint32_t w, uint32_t (&refs)[4]) {
+            int used = 0;
+            while (used < 4 && children[4 * (size_t)w + used] != kNoWideChild) {
+                refs[used] = children[4 * (size_t)w + used];
+                used++;
+            }
+            return used;
+        },
+        wroot, num_triangles, out, align_mode);
+}
 
 DevQNode quantize_node(const DevWideNode &src, const WideLayout &layout)
 {
     DevQNode q{};
-    int n = 0;
-    while (n < 4 && std::isfinite(src.lo[0][n])) n++;
-    uint32_t exps = 0;
-    for (int k = 0; k < 3; k++) {
-        double nlo = src.lo[k][0], nhi = src.hi[k][0];
-        for (int i = 1; i < n; i++) {
-            nlo = std::min<double>(nlo, src.lo[k][i]);
-            nhi = std::max<double>(nhi, src.hi[k][i]);
-        }
-        const double ext = nhi - nlo;
-        double margin = std::ldexp(std::max({std::fabs(nlo), std::fabs(nhi), ext}), -18);
-        if (!(margin > 0.0)) margin = std::ldexp(1.0, -100); // a node at the coordinate origin with no extent
-        // origin: a float at or below nlo - margin
-        float origin = (float)(nlo - margin);
-        if ((double)origin > nlo - margin) origin = std::nextafterf(origin, -std::numeric_limits<float>::infinity());
-        // step: the smallest float with a 2-bit mantissa (2^e * {1, 1.25, 1.5, 1.75}, ten bits in the
-        // node) with origin + 255 * step >= nhi + margin
-        const double want = (nhi + margin - (double)origin) / 255.0;
-        int e = 0;
-        (void)std::frexp(want, &e); // want = m * 2^e, m in [0.5, 1)
-        e = std::min(127, std::max(-126, e - 1));
-        uint32_t code = (uint32_t)(e + 127) << 2; // exponent << 2 | mantissa
-        auto step_of = [](uint32_t c) { return std::ldexp(1.0 + 0.25 * (double)(c & 3u), (int)(c >> 2) - 127); };
-        while (code < ((254u << 2) | 3u) && (double)origin + 255.0 * step_of(code) < nhi + margin) code++;
-        const double step = step_of(code);
-        q.origin[k] = origin;
-        exps |= code << (10 * k);
-        uint32_t lo_word = 0, hi_word = 0;
-        for (int i = 0; i < 4; i++) {
-            uint32_t bl = 255, bh = 0; // unused slot: near plane beyond far plane on every axis
-            if (i < n) {
-                const double lo = (double)src.lo[k][i] - margin, hi = (double)src.hi[k][i] + margin;
-                double fl = std::floor((lo - (double)origin) / step);
-                fl = std::min(255.0, std::max(0.0, fl));
-                while (fl > 0.0 && (double)origin + fl * step > lo + 0.5 * margin) fl -= 1.0;
-                double ch = std::ceil((hi - (double)origin) / step);
-                ch = std::min(255.0, std::max(0.0, ch));
-                while (ch < 255.0 && (double)origin + ch * step < hi - 0.5 * margin) ch += 1.0;
-                bl = (uint32_t)fl;
-                bh = (uint32_t)ch;
-            }
-            lo_word |= bl << (8 * i);
-            hi_word |= bh << (8 * i);
-        }
-        q.lo[k] = lo_word;
-        q.hi[k] = hi_word;
-    }
-    q.exps = exps;
+    const int n = wide_children_used(src);
+    quantize_planes(src, n, q);
     // children block: in slot order, the way layout_wide4 numbered it
-    uint32_t base = 0xFFFFFFFFu, meta = 0;
-    for (int i = 0; i < n; i++) {
-        const uint32_t ref = src.child[i];
-        uint32_t unit, tris;
-        if (ref & kLeafBit) {
-            unit = layout.slot_unit[(ref >> 3) & (kMaxPackedFirst - 1u)];
-            tris = (ref & 7u) + 1u;
-        } else {
-            unit = layout.node_unit[ref];
-            tris = 0;
-        }
-        if (i == 0) base = unit;
-        meta |= (((unit - base) << 2) | tris) << (8 * i);
-    }
-    for (int i = n; i < 4; i++) meta |= (meta & 0xFFu) << (8 * i);
-    q.base4 = base << 2;
-    q.meta = meta;
+    quantize_children(
+        n,
+        [&](int i) {
+            const uint32_t ref = src.child[i];
+            return (ref & kLeafBit) ? layout.slot_unit[(ref >> 3) & (kMaxPackedFirst - 1u)] : layout.node_unit[ref];
+        },
+        [&](int i) { return (src.child[i] & kLeafBit) ? (src.child[i] & 7u) + 1u : 0u; }, q);
     return q;
 }
 

@@ -54,6 +54,10 @@ struct WideLayout {
 // wroot: what collapse_wide4 returned.  False when a leaf holds more than kWideLeafTris triangles.
 bool layout_wide4(const std::vector<DevWideNode> &wide, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
                   unsigned align_mode = 0);
+// The same from the child references alone: four per wide node, unused slots hold kNoWideChild.
+constexpr uint32_t kNoWideChild = 0x7FFFFFFFu; // neither a leaf reference of a tree that fits nor a node index
+bool layout_wide4(const uint32_t *children, size_t num_wide, uint32_t wroot, uint32_t num_triangles, WideLayout &out,
+                  unsigned align_mode = 0);
 
 // One node on the 8-bit grid.  Per axis: origin is placed `margin` below the lowest child plane
 // and the grid step is the smallest value of the form (1 + m / 4) * 2^e, m in 0..3 (what the ten-bit step
