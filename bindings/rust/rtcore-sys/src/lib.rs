@@ -365,6 +365,12 @@ extern "C" {
         stats: *mut rt_bvh_stats,
     ) -> c_int;
     pub fn rt_scene_fast_tree_on_device(scene: *const rt_scene, out: *mut c_int) -> c_int;
+    pub fn rt_scene_get_wide_items(
+        scene: *const rt_scene,
+        units: *mut c_void,
+        capacity_units: u64,
+        num_units: *mut u64,
+    ) -> c_int;
     pub fn rt_scene_bounds(scene: *const rt_scene, lo: *mut f32, hi: *mut f32) -> c_int;
 }
 

@@ -193,8 +193,10 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *                       leaves of at most "fast_tree_max_leaf" triangles; 0 collapses it from the
  *                       reference's tree.  Forms 0 and 1 always walk the reference's tree.
  *   "fast_tree_device_build" 0 = the tree of forms 2 and 3 is built on the host, 1 (default) = on the
- *                       GPU for meshes of 2^18 triangles and more, 2 = always on the GPU.  The tree is the
- *                       same either way (rt_bvh_build_search_device).
+ *                       GPU for meshes of 2^18 triangles and more, 2 = always on the GPU, together with the
+ *                       4-wide collapse, quantization and packing of the traversal items; 3 = the binary
+ *                       tree on the GPU, the items on the host.  The tree and the items are the same either
+ *                       way (rt_bvh_build_search_device, rt_scene_get_wide_items).
  *   "fast_tree_max_leaf" 1..3 (default 2), read by rt_scene_create: most triangles in a leaf of
  *                       the tree of forms 2 and 3
  *   "fast_tree_align"   0, 1, 3 or 4 (default 4), read by rt_scene_create: placement of the 48-byte items of
@@ -270,8 +272,13 @@ int rt_bvh_build_search_device(rt_ctx *ctx, const float *positions, uint32_t num
 /* Box of all vertices of the scene's mesh (no counterpart in the reference; the library scales the
  * Morton keys of its ray-queue sorts with it). */
 int rt_scene_bounds(const rt_scene *scene, float lo[3], float hi[3]);
-/* *out = 1 when the scene's fast-form tree came from the device-side builder, 0 when from the host's */
+/* *out = 0 when the scene's fast-form tree came from the host builder, 1 when from the device-side builder,
+ * 2 when the traversal items (4-wide collapse, quantization, packing) were made on the device as well */
 int rt_scene_fast_tree_on_device(const rt_scene *scene, int *out);
+/* The traversal items of the fast forms as they lie in device memory: *num_units 16-byte units (a 4-wide
+ * quantized node or a triangle is three of them).  units may be NULL to ask for the count.  No counterpart
+ * in the reference; tests compare the device-made items with the host-made ones through it. */
+int rt_scene_get_wide_items(const rt_scene *scene, void *units, uint64_t capacity_units, uint64_t *num_units);
 
 /* 4-wide traversal form of the tree (no counterpart in the reference, whose tree
  * is binary, src/bvh.rs:19-34).

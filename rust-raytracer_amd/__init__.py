@@ -133,6 +133,7 @@ EXPORTS = {
                                              C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
     "rt_scene_fast_tree_on_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "rt_scene_bounds": (C.c_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
+    "rt_scene_get_wide_items": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rt_bvh_build_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
                                     C.POINTER(SceneInfo), C.POINTER(BvhStats)]),
     "rt_bvh_wide_host": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
@@ -433,10 +434,19 @@ class Scene:
         return np.array(lo[:], np.float32), np.array(hi[:], np.float32)
 
     def fast_tree_on_device(self):
-        """True when the tree of the fast traversal forms came from the device-side builder."""
+        """0: the tree of the fast traversal forms came from the host builder, 1: from the device-side
+        builder, 2: and its traversal items were made on the device too."""
         out = C.c_int(0)
         _check(_lib.rt_scene_fast_tree_on_device(self.h, C.byref(out)))
-        return bool(out.value)
+        return int(out.value)
+
+    def wide_items(self):
+        """The fast forms' traversal items as [units, 4] uint32 (rt_scene_get_wide_items)."""
+        n = C.c_uint64(0)
+        _check(_lib.rt_scene_get_wide_items(self.h, None, 0, C.byref(n)))
+        out = np.zeros((int(n.value), 4), dtype=np.uint32)
+        _check(_lib.rt_scene_get_wide_items(self.h, _p(out), n.value, C.byref(n)))
+        return out
 
     def bvh_stats(self):
         st = BvhStats()

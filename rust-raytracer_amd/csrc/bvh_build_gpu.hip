@@ -30,6 +30,8 @@
 #include <string>
 
 #include "bvh_build_gpu.hpp"
+#include "wide_bvh.hpp"
+#include "wide_node_ops.hpp"
 
 namespace rtc {
 namespace {
@@ -510,6 +512,131 @@ __global__ __launch_bounds__(256) void scatter_kernel(Prims src, Prims dst, cons
     node_of_next[to] = next;
 }
 
+// ------------------------------------------------------------------------
+// From the binary tree to the traversal items without leaving the device: 4-wide collapse breadth
+// first (the wide node of a binary node depends on that node's descendants alone, so a level of
+// wide nodes is one launch), quantization and packing per node and per triangle.  Only the placement
+// of the items -- a depth-first walk with a running position, wide_bvh.cpp: layout_wide4 -- stays
+// on the host, fed with the 16 bytes of child references per wide node.
+
+struct WidePending { // a wide node still to be made
+    uint32_t bin;    // the binary node it is collapsed from
+    uint32_t parent; // wide node whose slot refers to it, kNoParent for the root
+    uint32_t slot;
+};
+
+struct FlatTree { // the builder's node records as the collapse reads them
+    const rt_flat_node *nodes;
+    __device__ static uint32_t packed(uint32_t ref, uint32_t count)
+    {
+        return (ref & kLeaf) ? kLeafBit | ((ref & 0x7FFFFFFFu) << 3) | (count - 1u) : ref;
+    }
+    __device__ void children(uint32_t bin, WideSlot &l, WideSlot &r) const
+    {
+        const rt_flat_node &n = nodes[bin];
+        const float *b[3] = {n.bx, n.by, n.bz};
+        for (int k = 0; k < 3; k++) {
+            l.lo[k] = b[k][0];
+            r.lo[k] = b[k][1];
+            l.hi[k] = b[k][2];
+            r.hi[k] = b[k][3];
+        }
+        l.ref = packed(n.left, n.left_count);
+        r.ref = packed(n.right, n.right_count);
+    }
+};
+
+__global__ __launch_bounds__(256) void wide_collapse_kernel(const rt_flat_node *nodes, const WidePending *open,
+                                                            uint32_t count, uint32_t wide_base, DevWideNode *wide,
+                                                            uint32_t *inner_count)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const WidePending job = open[i];
+    WideSlot c[4];
+    const int n = collapse_slots(FlatTree{nodes}, job.bin, c);
+    fill_wide_node(c, n, job.bin, wide[wide_base + i]);
+    uint32_t inner = 0;
+    for (int k = 0; k < n; k++) inner += (c[k].ref & kLeafBit) ? 0u : 1u;
+    inner_count[i] = inner;
+    if (job.parent != kNoParent) wide[job.parent].child[job.slot] = wide_base + i;
+}
+
+// the inner children of this level's wide nodes are the next level's jobs, in node and slot order
+__global__ __launch_bounds__(256) void wide_children_kernel(const DevWideNode *wide, uint32_t count, uint32_t wide_base,
+                                                            const uint32_t *inner_scan, WidePending *next)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const DevWideNode &w = wide[wide_base + i];
+    const int n = wide_children_used(w);
+    uint32_t to = inner_scan[i];
+    for (int k = 0; k < n; k++)
+        if (!(w.child[k] & kLeafBit)) next[to++] = WidePending{w.child[k], wide_base + i, (uint32_t)k};
+}
+
+__global__ __launch_bounds__(256) void wide_child_refs_kernel(const DevWideNode *wide, uint32_t count, uint32_t *refs)
+{
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= count) return;
+    const int n = wide_children_used(wide[w]);
+    uint4 r;
+    r.x = wide[w].child[0];
+    r.y = n > 1 ? wide[w].child[1] : kNoWideChild;
+    r.z = n > 2 ? wide[w].child[2] : kNoWideChild;
+    r.w = n > 3 ? wide[w].child[3] : kNoWideChild;
+    reinterpret_cast<uint4 *>(refs)[w] = r;
+}
+
+__global__ __launch_bounds__(256) void wide_pack_nodes_kernel(const DevWideNode *wide, uint32_t count,
+                                                              const uint32_t *node_unit, const uint32_t *slot_unit,
+                                                              Unit *items)
+{
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= count) return;
+    const DevWideNode &src = wide[w];
+    DevQNode q;
+    const int n = wide_children_used(src);
+    quantize_planes(src, n, q);
+    quantize_children(
+        n,
+        [&](int i) {
+            const uint32_t ref = src.child[i];
+            return (ref & kLeafBit) ? slot_unit[(ref >> 3) & (kMaxPackedFirst - 1u)] : node_unit[ref];
+        },
+        [&](int i) { return (src.child[i] & kLeafBit) ? (src.child[i] & 7u) + 1u : 0u; }, q);
+    const uint4 *from = reinterpret_cast<const uint4 *>(&q);
+    uint4 *to = reinterpret_cast<uint4 *>(items + node_unit[w]);
+    to[0] = from[0];
+    to[1] = from[1];
+    to[2] = from[2];
+}
+
+// src/triangle_opt.rs:72-81 for the triangle in slot s of the leaf order, at its units
+__global__ __launch_bounds__(256) void wide_pack_tris_kernel(const float *pos, const uint32_t *idx, const uint32_t *order,
+                                                             uint32_t n, const uint32_t *slot_unit, Unit *items)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t t = order[s];
+    const float *a = pos + 3 * (size_t)idx[3 * (size_t)t + 0];
+    const float *b = pos + 3 * (size_t)idx[3 * (size_t)t + 1];
+    const float *c = pos + 3 * (size_t)idx[3 * (size_t)t + 2];
+    DevTri d;
+    for (int k = 0; k < 3; k++) {
+        d.v0[k] = a[k];
+        d.e1[k] = b[k] - a[k];
+        d.e2[k] = c[k] - a[k];
+    }
+    d.id = t;
+    d.pad[0] = d.pad[1] = 0;
+    const uint4 *from = reinterpret_cast<const uint4 *>(&d);
+    uint4 *to = reinterpret_cast<uint4 *>(items + slot_unit[s]);
+    to[0] = from[0];
+    to[1] = from[1];
+    to[2] = from[2];
+}
+
 struct DevMem { // frees what it holds when the build ends, however it ends
     std::vector<void *> blocks;
     ~DevMem()
@@ -533,8 +660,9 @@ struct DevMem { // frees what it holds when the build ends, however it ends
 } // namespace
 
 bool build_bvh_search_device(const float *positions, uint32_t nv, const uint32_t *indices, uint32_t nt,
-                             BuildTuning tune, HostBvh &out, std::string &why)
+                             BuildTuning tune, HostBvh &out, std::string &why, DeviceWideRequest *wide_request)
 {
+    if (wide_request) wide_request->done = false;
     const uint32_t nb = std::min<uint32_t>(std::max<uint32_t>(tune.buckets, 2), kMaxB);
     const uint32_t max_leaf = std::min<uint32_t>(std::max<uint32_t>(tune.max_leaf, 1), 8);
     if (nt <= max_leaf) {
@@ -680,16 +808,115 @@ bool build_bvh_search_device(const float *positions, uint32_t nv, const uint32_t
     GPU_TRY(hipStreamSynchronize(s));
     mark("levels");
     GPU_TRY(hipMemcpy(&h, tot, sizeof h, hipMemcpyDeviceToHost));
-    out.nodes.resize(h.num_nodes);
-    out.order.resize(nt);
-    if (h.num_nodes) GPU_TRY(hipMemcpy(out.nodes.data(), nodes, (size_t)h.num_nodes * sizeof(rt_flat_node), hipMemcpyDeviceToHost));
-    GPU_TRY(hipMemcpy(out.order.data(), prims[cur].order, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     out.root_ref = h.root_ref;
     out.root_count = h.root_count;
     out.stats.num_leaves = h.num_leaves;
     out.stats.num_objs = h.num_objs;
     out.stats.max_depth = h.max_depth;
     out.stats.max_objs = h.max_objs;
+
+    // ---- the traversal items, if asked for and the tree needs no leaf refinement on the host
+    if (wide_request && h.num_nodes != 0 && !(h.root_ref & kLeaf) && h.max_objs <= wide_request->leaf_tris &&
+        h.max_objs <= kWideLeafTris && wide_request->alloc) {
+        DeviceWideRequest &rq = *wide_request;
+        std::string wide_why;
+        const bool made = [&]() -> bool {
+#define WIDE_TRY(expr)                                                       \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) {                                              \
+            wide_why = std::string(#expr) + ": " + hipGetErrorString(e_);    \
+            (void)hipGetLastError();                                         \
+            return false;                                                    \
+        }                                                                    \
+    } while (0)
+            const size_t max_wide = h.num_nodes; // a wide node per binary node at most
+            DevWideNode *wide = nullptr;
+            WidePending *wopen[2] = {nullptr, nullptr};
+            uint32_t *wcount = nullptr, *wscan = nullptr, *refs = nullptr, *d_node_unit = nullptr, *d_slot_unit = nullptr;
+            if (!(mem.get(wide, max_wide) && mem.get(wopen[0], max_wide) && mem.get(wopen[1], max_wide) &&
+                  mem.get(wcount, max_wide) && mem.get(wscan, max_wide) && mem.get(refs, 4 * max_wide) &&
+                  mem.get(d_node_unit, max_wide) && mem.get(d_slot_unit, n))) {
+                wide_why = "device memory for the wide tree could not be allocated";
+                return false;
+            }
+            const WidePending first{h.root_ref, kNoParent, 0u};
+            WIDE_TRY(hipMemcpyAsync(wopen[0], &first, sizeof first, hipMemcpyHostToDevice, s));
+            uint32_t level = 0, wcur = 0, num_wide = 0, wlevel_count = 1;
+            while (wlevel_count != 0) {
+                if (num_wide + (size_t)wlevel_count > max_wide) {
+                    wide_why = "more wide nodes than binary nodes";
+                    return false;
+                }
+                const unsigned grid_w = (wlevel_count + 255u) / 256u;
+                hipLaunchKernelGGL(wide_collapse_kernel, dim3(grid_w), dim3(256), 0, s, nodes, wopen[wcur], wlevel_count,
+                                   num_wide, wide, wcount);
+                WIDE_TRY(rocprim::exclusive_scan(scan_temp, scan_bytes, wcount, wscan, 0u, (size_t)wlevel_count,
+                                                 rocprim::plus<uint32_t>(), s));
+                hipLaunchKernelGGL(wide_children_kernel, dim3(grid_w), dim3(256), 0, s, wide, wlevel_count, num_wide, wscan,
+                                   wopen[wcur ^ 1]);
+                uint32_t last[2] = {0, 0};
+                WIDE_TRY(hipMemcpyAsync(&last[0], wcount + (wlevel_count - 1), 4, hipMemcpyDeviceToHost, s));
+                WIDE_TRY(hipMemcpyAsync(&last[1], wscan + (wlevel_count - 1), 4, hipMemcpyDeviceToHost, s));
+                WIDE_TRY(hipStreamSynchronize(s));
+                WIDE_TRY(hipGetLastError());
+                num_wide += wlevel_count;
+                wlevel_count = last[0] + last[1];
+                wcur ^= 1;
+                level++;
+            }
+            mark("4-wide collapse");
+            // placement on the host, from the child references
+            std::vector<uint32_t> host_refs(4 * (size_t)num_wide);
+            hipLaunchKernelGGL(wide_child_refs_kernel, dim3((num_wide + 255u) / 256u), dim3(256), 0, s, wide, num_wide, refs);
+            WIDE_TRY(hipMemcpy(host_refs.data(), refs, host_refs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            WideLayout layout;
+            // a children block spread beyond its six address bits by alignment gaps: the packed placement always fits
+            if (!layout_wide4(host_refs.data(), num_wide, 0u, nt, layout, rq.align_mode) &&
+                (rq.align_mode == 0 || !layout_wide4(host_refs.data(), num_wide, 0u, nt, layout, 0))) {
+                wide_why = "the wide tree cannot be placed";
+                return false;
+            }
+            if (layout.num_units >= (1u << 30)) {
+                wide_why = "more than 2^30 units in the wide tree";
+                return false;
+            }
+            mark("layout (host)");
+            const size_t units = (size_t)layout.num_units + 1; // one spare unit: a wave-uniform item is read as 64 bytes
+            Unit *items = rq.alloc(units);
+            if (!items) {
+                wide_why = "device memory for the traversal items could not be allocated";
+                return false;
+            }
+            WIDE_TRY(hipMemcpyAsync(d_node_unit, layout.node_unit.data(), (size_t)num_wide * 4, hipMemcpyHostToDevice, s));
+            WIDE_TRY(hipMemcpyAsync(d_slot_unit, layout.slot_unit.data(), n * 4, hipMemcpyHostToDevice, s));
+            WIDE_TRY(hipMemsetAsync(items, 0, units * sizeof(Unit), s)); // gaps and the spare unit read as zeros
+            hipLaunchKernelGGL(wide_pack_nodes_kernel, dim3((num_wide + 255u) / 256u), dim3(256), 0, s, wide, num_wide,
+                               d_node_unit, d_slot_unit, items);
+            hipLaunchKernelGGL(wide_pack_tris_kernel, dim3(grid_n), dim3(256), 0, s, d_pos, d_idx, prims[cur].order, nt,
+                               d_slot_unit, items);
+            WIDE_TRY(hipStreamSynchronize(s));
+            WIDE_TRY(hipGetLastError());
+            mark("quantize + pack");
+            rq.num_units = (uint32_t)units;
+            rq.root_ref = layout.root_ref;
+            rq.wide_depth = level;
+            rq.num_wide_nodes = num_wide;
+            return true;
+#undef WIDE_TRY
+        }();
+        if (made) {
+            rq.done = true;
+            out.nodes.clear();
+            out.order.clear();
+            return true;
+        }
+        rq.why = wide_why;
+    }
+    out.nodes.resize(h.num_nodes);
+    out.order.resize(nt);
+    if (h.num_nodes) GPU_TRY(hipMemcpy(out.nodes.data(), nodes, (size_t)h.num_nodes * sizeof(rt_flat_node), hipMemcpyDeviceToHost));
+    GPU_TRY(hipMemcpy(out.order.data(), prims[cur].order, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     mark("download");
 #undef GPU_TRY
     return true;

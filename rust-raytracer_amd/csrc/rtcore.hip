@@ -200,6 +200,7 @@ struct rt_scene {
     uint32_t num_wide_nodes = 0;
     uint32_t num_wide_units = 0; // 16-byte units of the wide tree's item array
     bool fast_tree_on_device = false; // the search tree came from the device-side builder
+    bool fast_items_on_device = false; // and so did the traversal items made from it
     uint32_t stack_bound = 0; // entries a lane's traversal stack can need on this scene
     SceneDev dev{};
     uint64_t device_bytes = 0;
@@ -460,7 +461,7 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
         ctx->fuse_primary = (unsigned)value;
     } else if (n == "fast_tree_buckets" && (value == 0 || in(2, 64))) {
         ctx->fast_tree_buckets = (unsigned)value;
-    } else if (n == "fast_tree_device_build" && in(0, 2)) {
+    } else if (n == "fast_tree_device_build" && in(0, 3)) {
         ctx->fast_tree_device_build = (unsigned)value;
     } else if (n == "fast_tree_max_leaf" && in(1, kWideLeafTris)) {
         ctx->fast_tree_max_leaf = (unsigned)value;
@@ -934,10 +935,11 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
     unsigned device_build = ctx->fast_tree_device_build;
     if (const char *env = getenv("RTCORE_FAST_TREE_DEVICE_BUILD")) {
         const int v = atoi(env);
-        if (v >= 0 && v <= 2) device_build = (unsigned)v;
+        if (v >= 0 && v <= 3) device_build = (unsigned)v;
     }
-    const bool on_device = search_buckets >= 2 && (device_build == 2 || (device_build == 1 && num_triangles >= (1u << 18)));
+    const bool on_device = search_buckets >= 2 && (device_build >= 2 || (device_build == 1 && num_triangles >= (1u << 18)));
     sc->fast_tree_on_device = false;
+    sc->fast_items_on_device = false;
     if (search_buckets >= 2) {
         // the reference pipeline on a thread of its own, the fast one here (the GPU build needs this
         // thread's device)
@@ -954,20 +956,44 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
             ~Joiner() { if (t.joinable()) t.join(); }
         } ref_joiner{ref_thread};
         const BuildTuning tune{search_buckets, leaf_tris};
+        DeviceWideRequest wide_rq;
         if (on_device) {
             std::string why;
-            sc->fast_tree_on_device = build_bvh_search_device(positions, num_vertices, indices, num_triangles, tune, hs, why);
-            phase("search tree (device)");
+            // the items too, unless the host is asked to make them (fast_tree_device_build 3: the device builds
+            // the binary tree only; for comparisons)
+            wide_rq.align_mode = align_mode;
+            wide_rq.leaf_tris = leaf_tris;
+            wide_rq.alloc = [&](size_t units) -> Unit * {
+                return sc->witems.ensure(units * sizeof(Unit)) == RT_OK ? (Unit *)sc->witems.p : nullptr;
+            };
+            sc->fast_tree_on_device = build_bvh_search_device(positions, num_vertices, indices, num_triangles, tune, hs, why,
+                                                             device_build == 3 ? nullptr : &wide_rq);
+            phase(wide_rq.done ? "search tree and items (device)" : "search tree (device)");
             if (!sc->fast_tree_on_device && verbose)
                 fprintf(stderr, "rt_scene_create: device build not used: %s\n", why.c_str());
+            if (sc->fast_tree_on_device && !wide_rq.done && !wide_rq.why.empty() && verbose)
+                fprintf(stderr, "rt_scene_create: items made on the host: %s\n", wide_rq.why.c_str());
         }
         if (!sc->fast_tree_on_device) {
             build_bvh(positions, num_vertices, indices, num_triangles, threads, hs, &tune);
             phase("search tree (host)");
         }
-        fast_pipeline(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, hs.order, hs.stats.max_depth,
-                      hs.stats.max_objs);
-        phase("refine, collapse, layout, pack");
+        if (wide_rq.done) {
+            sc->fast_items_on_device = true;
+            sc->num_wide_nodes = wide_rq.num_wide_nodes;
+            sc->num_wide_units = wide_rq.num_units;
+            num_items = wide_rq.num_units;
+            layout.root_ref = wide_rq.root_ref;
+            layout.num_units = wide_rq.num_units - 1u;
+            wide_depth = wide_rq.wide_depth;
+            fast_depth = hs.stats.max_depth;
+            extra_depth = 0;
+            sc->device_bytes += (size_t)wide_rq.num_units * sizeof(Unit);
+        } else {
+            fast_pipeline(hs.nodes.data(), hs.nodes.size(), hs.root_ref, hs.root_count, hs.order, hs.stats.max_depth,
+                          hs.stats.max_objs);
+            phase("refine, collapse, layout, pack");
+        }
         ref_thread.join();
         if (ref_error) std::rethrow_exception(ref_error);
         phase("reference pipeline (rest)");
@@ -993,7 +1019,7 @@ static int scene_prepare(rt_ctx *ctx, rt_scene *sc, const float *positions, uint
         return RT_OK;
     };
     rc = upload(sc->nodes, dn.data(), dn.size() * sizeof(DevNode));
-    if (rc == RT_OK) rc = upload(sc->witems, items.get(), num_items * sizeof(Unit));
+    if (rc == RT_OK && !sc->fast_items_on_device) rc = upload(sc->witems, items.get(), num_items * sizeof(Unit));
     if (rc == RT_OK) rc = upload(sc->tris, dt.get(), (size_t)num_triangles * sizeof(DevTri));
     if (rc == RT_OK) rc = upload(sc->big, big.data(), big.size() * sizeof(BigLeaf));
     if (rc == RT_OK) rc = upload(sc->normals, n4.get(), (size_t)num_triangles * 4 * sizeof(float));
@@ -1105,10 +1131,22 @@ extern "C" int rt_scene_bounds(const rt_scene *sc, float lo[3], float hi[3])
     return RT_OK;
 }
 
+extern "C" int rt_scene_get_wide_items(const rt_scene *sc, void *units, uint64_t capacity_units, uint64_t *num_units)
+{
+    if (!sc || !num_units) return fail(RT_ERR_INVALID, "rt_scene_get_wide_items: NULL argument");
+    *num_units = sc->dev.witems ? sc->num_wide_units : 0;
+    if (!units) return RT_OK;
+    if (capacity_units < *num_units)
+        return fail(RT_ERR_INVALID, "rt_scene_get_wide_items: room for %llu units, the tree has %llu",
+                    (unsigned long long)capacity_units, (unsigned long long)*num_units);
+    if (*num_units) HIP_TRY(hipMemcpy(units, sc->dev.witems, (size_t)*num_units * sizeof(Unit), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 extern "C" int rt_scene_fast_tree_on_device(const rt_scene *sc, int *out)
 {
     if (!sc || !out) return fail(RT_ERR_INVALID, "rt_scene_fast_tree_on_device: NULL argument");
-    *out = sc->fast_tree_on_device ? 1 : 0;
+    *out = sc->fast_items_on_device ? 2 : sc->fast_tree_on_device ? 1 : 0;
     return RT_OK;
 }
 

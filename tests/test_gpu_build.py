@@ -102,7 +102,7 @@ def test_scene_over_device_tree(O, rt, ctx_default, scenes):
         for mode in (0, 2):
             c.set_option("fast_tree_device_build", mode)
             Sg = rt.Scene(c, sc.positions, sc.indices, sc.geom_normals)
-            assert Sg.fast_tree_on_device() == (mode == 2)
+            assert Sg.fast_tree_on_device() == mode   # 2: tree and traversal items made on the device
             c.set_option("traversal_stream", 2)
             ids, t, _ = Sg.intersect_stream(rays, stats=False)
             occ, _ = Sg.occluded_stream(rays, stats=False)
@@ -115,3 +115,35 @@ def test_scene_over_device_tree(O, rt, ctx_default, scenes):
     assert np.array_equal(out[0][1], out[2][1]) and np.array_equal(out[0][2], out[2][2])
     assert (out[0][0] != out[2][0]).mean() < 1e-3
     assert out[0][4] == out[2][4] and np.allclose(out[0][3], out[2][3], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,kw", [("sponza-class", {}), ("test-mesh", {"n_tris": 20000, "seed": 3}),
+                                     ("cornell-class", {}), ("dragon-class", {})])
+@pytest.mark.parametrize("align,max_leaf", [(4, 2), (0, 3), (3, 1)])
+def test_device_made_items_are_the_hosts(rt, ctx_default, scenes, name, kw, align, max_leaf):
+    """The traversal items of the fast forms -- 4-wide collapse, quantization, placement, packing --
+    made on the device (fast_tree_device_build 2) against the host pipeline over the same device-built
+    binary tree (3): the unit array is equal bit for bit, for every placement mode and leaf size."""
+    c = ctx_default
+    sc = scenes.load(name, **kw)
+    items, made = {}, {}
+    try:
+        c.set_option("fast_tree_align", align)
+        c.set_option("fast_tree_max_leaf", max_leaf)
+        for mode in (2, 3):
+            c.set_option("fast_tree_device_build", mode)
+            Sg = rt.Scene(c, sc.positions, sc.indices, sc.geom_normals)
+            # a tree with a leaf above max_leaf (triangles the binning cannot separate) goes through the host's
+            # leaf refinement, whichever mode is asked for
+            made[mode] = Sg.fast_tree_on_device()
+            assert made[mode] in ((1, 2) if mode == 2 else (1,))
+            items[mode] = Sg.wide_items()
+            Sg.close()
+    finally:
+        c.set_option("fast_tree_device_build", 1)
+        c.set_option("fast_tree_align", 4)
+        c.set_option("fast_tree_max_leaf", 2)
+    assert items[2].shape == items[3].shape and items[2].shape[0] > 3
+    assert np.array_equal(items[2], items[3])
+    if max_leaf >= 2 and name != "cornell-class":
+        assert made[2] == 2
