@@ -150,7 +150,11 @@ void rt_ctx_destroy(rt_ctx *ctx);
  *   "coop_steps"        loop iterations after which a ray is finished by its whole
  *                       wave (0 = never; default 4096).  Rays handled that way keep their exact
  *                       hit distance; their visit counters and the id on an
- *                       exact-distance tie may differ from the single-lane walk.
+ *                       exact-distance tie may differ from the single-lane walk.  Sets
+ *                       "coop_steps_binary" as well.
+ *   "coop_steps_binary" the same for the forms on the binary tree alone (0, 1, 4; default 512: their
+ *                       rays take about twice the iterations, and the unoccluded shadow rays of the
+ *                       left-first any-hit walk are the longest of all)
  *   "min_active"        1..64, a wave fetches new rays when fewer lanes are busy (default 40);
  *   "min_active_depth0" the same for the depth-0 launches of rt_render (default 20: their rays
  *                       are coherent and a refill costs more than a few idle lanes)

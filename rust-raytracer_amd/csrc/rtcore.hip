@@ -131,7 +131,8 @@ struct rt_ctx {
     DevBuf fetch; // ray-fetch counters of the stream entry points
     DevBuf coop;  // wave-private work stacks of the cooperative straggler path
     unsigned coop_cap = 2048;    // entries per wave
-    unsigned coop_steps = 4096;  // a ray is handed to its whole wave after this many loop iterations
+    unsigned coop_steps = 4096;  // a ray is handed to its whole wave after this many loop iterations (4-wide forms)
+    unsigned coop_steps_binary = 512; // the same for the forms on the binary tree, whose stragglers cost more
     // refill threshold [depth 0 of rt_render: 0, everything else: 1][closest-hit: 0, any-hit: 1].  The
     // depth-0 launches run the while-while forms on coherent rays, where a refill (for the fused
     // primary launch: making the camera rays) costs more than a few idle lanes do: 20 is 4 % faster than
@@ -257,7 +258,10 @@ static void fill_coop(const rt_ctx *ctx, const rt_scene *sc, TraceLaunch &tl, bo
     // the binary finisher keeps max_depth + 2 entries in reserve, the wide one 3 * wide depth + 8, on top
     // of a lane's whole stack and one batch of 64
     const unsigned reserve = std::max(sc->dev.max_depth + 2u, 3u * sc->dev.wmax_depth + 8u);
-    tl.coop_steps = (reserve + 4u * 64u + sc->stack_bound < ctx->coop_cap) ? ctx->coop_steps : 0xFFFFFFFFu;
+    const bool binary = tl.mode == 0 || tl.mode == 1 || tl.mode == 4 || !sc->dev.witems;
+    tl.coop_steps = (reserve + 4u * 64u + sc->stack_bound < ctx->coop_cap)
+                        ? (binary ? ctx->coop_steps_binary : ctx->coop_steps)
+                        : 0xFFFFFFFFu;
     // a triangle job of the queued form holds a unit index in 26 bits (1 GB of wide-tree items)
     tl.job_units_ok = sc->num_wide_units < (1u << 26) ? 1u : 0u;
 }
@@ -356,7 +360,11 @@ extern "C" int rt_ctx_create(int device_id, rt_ctx **out)
     if (const char *env = getenv("RTCORE_SORT_OCTANT")) ctx->sort_octant = atoi(env) != 0;
     if (const char *env = getenv("RTCORE_COOP_STEPS")) {
         long long v = atoll(env);
-        ctx->coop_steps = (v <= 0 || v >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)v;
+        ctx->coop_steps = ctx->coop_steps_binary = (v <= 0 || v >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)v;
+    }
+    if (const char *env = getenv("RTCORE_COOP_STEPS_BINARY")) {
+        long long v = atoll(env);
+        ctx->coop_steps_binary = (v <= 0 || v >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)v;
     }
     if (const char *env = getenv("RTCORE_MIN_ACTIVE_EXTEND")) {
         int v = atoi(env);
@@ -448,7 +456,9 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *name, int64_t value)
     const std::string n(name);
     auto in = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
     if (n == "coop_steps") {
-        ctx->coop_steps = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
+        ctx->coop_steps = ctx->coop_steps_binary = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
+    } else if (n == "coop_steps_binary") {
+        ctx->coop_steps_binary = (value <= 0 || value >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (unsigned)value;
     } else if (n == "min_active" && in(1, 64)) {
         ctx->min_active[1][0] = ctx->min_active[1][1] = (unsigned)value;
     } else if (n == "min_active_depth0" && in(1, 64)) {
