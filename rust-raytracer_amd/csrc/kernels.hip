@@ -339,6 +339,22 @@ __device__ __forceinline__ float vmin3(float a, float b, float c)
 // Runs the lane's ray until it is done (s.cur == kDone) or until fewer than
 // `min_active` lanes of the wave are still traversing (the wave then goes back
 // to fetch rays for its idle lanes).
+// Which child an any-hit walk of the binary tree takes first when both are hit.  The reference goes left
+// (src/bvh/intersect1.rs:7-106), and with visit counters asked for so does this walk.  Without them the
+// order is free: the far distance of an any-hit ray never changes, so which leaves the walk can reach --
+// and with that the answer -- does not depend on the order, only how soon an occluder is found does.
+// RTC_ANYHIT_BINARY_ORDER 0: left first; 1: the child entered first; 2: the child the ray stays in longer.
+#ifndef RTC_ANYHIT_BINARY_ORDER
+#define RTC_ANYHIT_BINARY_ORDER 2
+#endif
+template <bool STATS>
+__device__ __forceinline__ bool anyhit_left_first(float nearl, float farl, float nearr, float farr)
+{
+    if (STATS || RTC_ANYHIT_BINARY_ORDER == 0) return true;
+    if (RTC_ANYHIT_BINARY_ORDER == 1) return nearl <= nearr;
+    return farl - nearl >= farr - nearr;
+}
+
 template <bool ANYHIT, bool STATS, class STACK>
 __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK &st,
                                          Counters &cnt, unsigned min_active, unsigned max_steps)
@@ -385,7 +401,7 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, LaneState &s, STACK
             const bool hl = nearl <= farl;
             const bool hr = nearr <= farr;
             const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
-            const bool left_first = ANYHIT ? true : (nearl <= nearr);
+            const bool left_first = ANYHIT ? anyhit_left_first<STATS>(nearl, farl, nearr, farr) : (nearl <= nearr);
             const unsigned first = left_first ? left : right;
             const unsigned second = left_first ? right : left;
             const bool hf = left_first ? hl : hr;
@@ -527,7 +543,9 @@ __device__ __forceinline__ void traverse_steps(const SceneDev &sc, LaneState &s,
             const bool hl = nearl <= farl;
             const bool hr = nearr <= farr;
             const unsigned left = __float_as_uint(lk.x), right = __float_as_uint(lk.y);
-            const bool left_first = (ANYHIT || SINGLE) ? true : (nearl <= nearr);
+            const bool left_first = SINGLE   ? true
+                                    : ANYHIT ? anyhit_left_first<STATS>(nearl, farl, nearr, farr)
+                                             : (nearl <= nearr);
             const unsigned first = left_first ? left : right;
             const unsigned second = left_first ? right : left;
             const bool hf = left_first ? hl : hr;
@@ -766,10 +784,16 @@ __device__ __forceinline__ bool qwide_step(const float4 a0, const float4 a1, con
         // Hit children nearest first: the entry distance (never negative, so its bits order like an
         // unsigned) with the slot number in the two lowest mantissa bits, sorted by a 4-input network
         // of unsigned min/max; ties go to the lower slot.
-        unsigned k0 = n[0] <= f[0] ? (__float_as_uint(n[0]) & ~3u) | 0u : kMissKey;
-        unsigned k1 = n[1] <= f[1] ? (__float_as_uint(n[1]) & ~3u) | 1u : kMissKey;
-        unsigned k2 = n[2] <= f[2] ? (__float_as_uint(n[2]) & ~3u) | 2u : kMissKey;
-        unsigned k3 = n[3] <= f[3] ? (__float_as_uint(n[3]) & ~3u) | 3u : kMissKey;
+        // (any-hit with RTC_ANYHIT_SORTED 2: by the length of the ray's stay in the box instead, longest first:
+        // the bits of a non-negative length, inverted)
+        const bool by_stay = ANYHIT && RTC_ANYHIT_SORTED == 2;
+#define RTC_CHILD_KEY(i) \
+    (n[i] <= f[i] ? ((by_stay ? ~__float_as_uint(f[i] - n[i]) & 0x7FFFFFFFu : __float_as_uint(n[i])) & ~3u) | (unsigned)(i) : kMissKey)
+        unsigned k0 = RTC_CHILD_KEY(0);
+        unsigned k1 = RTC_CHILD_KEY(1);
+        unsigned k2 = RTC_CHILD_KEY(2);
+        unsigned k3 = RTC_CHILD_KEY(3);
+#undef RTC_CHILD_KEY
         RTC_CE(k0, k1);
         RTC_CE(k2, k3);
         RTC_CE(k0, k2);
