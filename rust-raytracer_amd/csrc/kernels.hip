@@ -1356,6 +1356,14 @@ __device__ __forceinline__ void traverse_wide(const SceneDev &sc, LaneState &s, 
 #endif
         while (!(cur & 3u) && steps < max_steps) { // kDone has its low bits set
             steps++;
+#if RTC_PROBE_VALU
+            {   // measurement builds only: RTC_PROBE_VALU more vector instructions per node iteration
+                float x = r.near_t;
+#pragma unroll
+                for (int k = 0; k < RTC_PROBE_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));
+                asm volatile("" ::"v"(x));
+            }
+#endif
             const unsigned ucur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
             bool pop;
             if (__ballot(cur != ucur) == 0) { // every lane still in this loop is at node ucur
