@@ -148,7 +148,7 @@ int rt_ctx_create(int device_id, rt_ctx **out);
 void rt_ctx_destroy(rt_ctx *ctx);
 /* Tuning knobs (no reference counterpart).  Names and ranges:
  *   "coop_steps"        loop iterations after which a ray is finished by its whole
- *                       wave (0 = never; default 4096).  Rays handled that way keep their exact
+ *                       wave (0 = never; default 1024).  Rays handled that way keep their exact
  *                       hit distance; their visit counters and the id on an
  *                       exact-distance tie may differ from the single-lane walk.  Sets
  *                       "coop_steps_binary" as well.

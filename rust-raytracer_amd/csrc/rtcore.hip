@@ -131,7 +131,7 @@ struct rt_ctx {
     DevBuf fetch; // ray-fetch counters of the stream entry points
     DevBuf coop;  // wave-private work stacks of the cooperative straggler path
     unsigned coop_cap = 2048;    // entries per wave
-    unsigned coop_steps = 4096;  // a ray is handed to its whole wave after this many loop iterations (4-wide forms)
+    unsigned coop_steps = 1024;  // a ray is handed to its whole wave after this many loop iterations (4-wide forms)
     unsigned coop_steps_binary = 512; // the same for the forms on the binary tree, whose stragglers cost more
     // refill threshold [depth 0 of rt_render: 0, everything else: 1][closest-hit: 0, any-hit: 1].  The
     // depth-0 launches run the while-while forms on coherent rays, where a refill (for the fused

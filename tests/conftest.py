@@ -34,7 +34,7 @@ def scenes():
 
 
 # Library defaults of every option a test may change, and what the exact configuration sets on top.
-OPTION_DEFAULTS = {"coop_steps": 4096, "coop_steps_binary": 512, "min_active": 40, "min_active_depth0": 20, "traversal_depth0": 3, "traversal_deep": 2,
+OPTION_DEFAULTS = {"coop_steps": 1024, "coop_steps_binary": 512, "min_active": 40, "min_active_depth0": 20, "traversal_depth0": 3, "traversal_deep": 2,
                    "traversal_stream": 1, "fuse_primary": 1, "sort_extend_from": 0xFFFFFFFF,
                    "sort_connect_from": 1, "sort_bits": 21, "sort_octant": 0, "timing": 1, "overlap_connect": 0,
                    "traversal_deep_connect": -1, "fast_tree_max_leaf": 2, "fast_tree_align": 4, "fast_tree_device_build": 1, "workspace_limit_mb": 0}

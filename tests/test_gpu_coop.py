@@ -9,7 +9,7 @@ Moeller-Trumbore with a division), so where two surfaces meet within rounding
 the marginally closer triangle and the other not.  Bar for such rays: the same
 hit/miss decision, hit distances within 2e-6 relative (a few ulps), ids equal
 wherever the distances are equal, and only a small fraction of rays affected.
-With the library default (4096 steps) only rays that need more steps than that
+With the library default (1024 steps on the wide tree, 512 on the binary one) only rays that need more steps than that
 take this path at all."""
 import numpy as np
 import pytest
