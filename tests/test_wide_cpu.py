@@ -359,3 +359,23 @@ def test_builders_do_not_depend_on_the_thread_count(rt, scenes):
         for th in (3, 8):
             n, o, i, s = build(th)
             assert n.tobytes() == n1.tobytes() and np.array_equal(o, o1) and i == i1 and s == s1
+
+
+def test_parallel_partition_on_skewed_ranges(rt):
+    """The top levels partition large ranges on all threads (the reference's in-place partition, element for
+    element).  A mesh whose splits are very uneven -- 97 % of the triangles in a small cluster, the rest spread
+    thinly, and a run of exact duplicates -- must give the single-threaded tree whatever the thread count."""
+    rng = np.random.default_rng(41)
+    n = 220000                                                 # above the 200,000 from which the builders use their threads
+    c = np.concatenate([rng.normal(0.0, 0.01, (n * 97 // 100, 3)), rng.uniform(-50.0, 50.0, (n - n * 97 // 100, 3))])
+    c[1000:3000] = c[1000]                                     # coincident centroids inside the cluster
+    rng.shuffle(c)
+    tri = np.array([[0, 0, 0], [1e-3, 0, 0], [0, 1e-3, 0]], np.float32)
+    pos = (c[:, None, :].astype(np.float32) + tri[None, :, :]).reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    for build in (lambda th: rt.build_bvh_host(pos, idx, threads=th),
+                  lambda th: rt.build_bvh_search_host(pos, idx, 32, 2, threads=th)):
+        n1, o1, i1, s1 = build(1)
+        for th in (2, 7, 16):
+            nn, oo, ii, ss = build(th)
+            assert nn.tobytes() == n1.tobytes() and np.array_equal(oo, o1) and ii == i1 and ss == s1, th
